@@ -1,0 +1,173 @@
+/* mrf.h -- C ABI of the MI355X-native multi-robot fabrics hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own: the
+ * path is a Python object API that ends in CasADi function evaluations
+ *   planner.compute_action(**kwargs)                  examples/example_pandas_Jointspace.py:441,444
+ *   ForwardFabricsPlanner.get_velocity_rollouts(...)  multi_robot_fabrics/fabrics_planner/forward_planner_Jointspace.py:298-336
+ *   ForwardFabricsPlanner.rollouts_numerical(...)     forward_planner_Jointspace.py:338-423
+ *   FabricsRollouts.get_velocity_rollouts / rollouts_numerical
+ *                                                     multi_robot_fabrics/fabrics_planner/forward_planner_Cartesian.py:538-563
+ *   fk / jac / jac_dot helper functions               multi_robot_fabrics/utils/utils.py:16-54,87-119
+ * Every entry point below states which of those it replaces.  Plain pointers and sizes only;
+ * no torch types, no exceptions, no global mutable state.
+ *
+ * Conventions
+ *   - All device arrays are caller-owned, never retained past the call, and laid out
+ *     component-major over the batch ("SoA"):  a[c][row]  ==  a[c * rows + row].
+ *   - A "row" is one (scenario, robot) pair:  row = scenario * n_robots + robot.
+ *     The robot index (row % n_robots) selects the mount transform.
+ *   - The scalar type of every array is cfg.scalar (f64 or f32) for the whole handle.
+ *   - Calls are asynchronous on the given hipStream_t (passed as void*; NULL = default stream).
+ *   - Return 0 on success, a negative mrf_status otherwise; mrf_last_error() gives text.
+ *   - A handle is NOT thread-safe; distinct handles are independent.
+ */
+#ifndef MRF_H_
+#define MRF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRF_ABI_VERSION 1
+#define MRF_MAX_ROBOTS 16
+#define MRF_MAX_SPHERES 32 /* exchanged spheres per robot */
+#define MRF_DOF_MAX 7
+#define MRF_N_EGO 6 /* ego collision points of a Panda: origins of panda_link3..8 */
+
+/* per-row parameter vector (29 scalars), the runtime kwargs of compute_action
+ * (example_pandas_Jointspace.py:421-439) minus the obstacle lists */
+#define MRF_P_X_GOAL_0 0      /* [3]  (planar3: [2])                         */
+#define MRF_P_WEIGHT_GOAL_0 3 /*                                              */
+#define MRF_P_ANGLE_GOAL_1 4  /* [9]  row-major 3x3                           */
+#define MRF_P_X_GOAL_1 13     /* [3]                                          */
+#define MRF_P_WEIGHT_GOAL_1 16
+#define MRF_P_X_GOAL_2 17
+#define MRF_P_WEIGHT_GOAL_2 18
+#define MRF_P_CONSTRAINT_0 19 /* [4]  plane a.x + d                           */
+#define MRF_P_RADIUS_BODY 23  /* [6]  links 3..8 (planar3: [1] base_link)     */
+#define MRF_NPARAM 29
+
+typedef enum { MRF_OK = 0, MRF_E_ARG = -1, MRF_E_CONFIG = -2, MRF_E_DEVICE = -3, MRF_E_LAUNCH = -4 } mrf_status;
+typedef enum { MRF_MODEL_PANDA7 = 0, MRF_MODEL_PLANAR3 = 1 } mrf_model;
+typedef enum { MRF_MODE_ACC = 0, MRF_MODE_VEL = 1 } mrf_mode;
+typedef enum { MRF_F64 = 0, MRF_F32 = 1 } mrf_scalar;
+typedef enum { MRF_FAMILY_POW = 0, MRF_FAMILY_LOGISTIC = 1 } mrf_family;
+typedef enum { MRF_GATE_NONE = 0, MRF_GATE_NEG = 1 } mrf_gate;
+
+/* One leaf string of the reference, reduced to its family.  The strings the reference
+ * passes (example_pandas_Jointspace.py:87-89, example_pointmasses_static.py:106-107) are
+ *   POW      :  k / x**p * gate(xdot) * xdot**2
+ *   LOGISTIC :  k * (1/(1 + c*exp(-s*x)) - 1) * gate(xdot) * xdot**2
+ * gate NEG is (1 - heaviside(xdot)) == -0.5*(sign(xdot)-1): 1 for xdot<0, 0 for xdot>0, 0.5 at 0.
+ * As a geometry the value is h(x,xdot); as a Finsler energy L the metric is d2L/dxdot2. */
+typedef struct {
+  int32_t family;
+  int32_t gate;
+  int32_t p;
+  int32_t reserved;
+  double k, c, s;
+} mrf_leaf_fn;
+
+typedef struct {
+  int32_t abi_version; /* MRF_ABI_VERSION */
+  int32_t model;       /* mrf_model */
+  int32_t scalar;      /* mrf_scalar */
+  int32_t mode;        /* mrf_mode: action = qddot | qdot + dt*qddot   (EXJ:133) */
+  int32_t n_robots;    /* N: robots per scenario */
+  int32_t n_spheres;   /* S: exchanged spheres per robot in rollouts (reference: 8 link origins) */
+  int32_t horizon;     /* H */
+  int32_t dynamic;     /* STATIC_OR_DYN_FABRICS: 0 zeroes the exchanged v,a (FPJ:215-217) */
+  int32_t n_ego;       /* 6 = collision+plane leaves on links 3..8; 0 = "grasp" planner (EXJ:160-166); planar3: 1 or 0 */
+  int32_t n_planes;    /* 0 or 1 plane constraint per ego point */
+  int32_t use_limits;  /* joint-limit leaves on/off */
+  int32_t n_goals;     /* attractors in use: panda 0..3, planar3 0..1 */
+  int32_t plane_abs;   /* |a.x+d| in the plane task map */
+  int32_t zero_small_action; /* action := 0 when |action| < eps */
+  int32_t obst_dim;    /* dynamic_obstacle_dimension: 3 (pandas) or 2 (point robots, dynamic example) */
+  int32_t goal_estimate_mask; /* bit i: robot i's x_goal_0 is replaced by x_ee + goal_estimate_T * v_ee at rollout start (EXC:355-357) */
+  double dt;           /* planner time step (PM:8) */
+  double eps;          /* regulariser in (M + eps I)^-1 and in the energization denominators */
+  double jdot_sign;    /* sign in c = jdot_sign * d(J qdot)/dq qdot   (utils.py:28) */
+  double goal_estimate_T; /* 20*0.01 (EXJ:347) */
+  double base_mass;    /* base energy 0.5*m*qdot.qdot */
+  double attr_k, attr_alpha;        /* psi = w*k*(|x| + log(1+exp(-2 alpha |x|))/alpha) */
+  double attr_mu, attr_ml, attr_a;  /* A = (mu-ml)*exp(-(a|x|)^2) + ml ;  L = xdot^T A xdot */
+  double beta_a, beta_r, beta_b, beta_s; /* 0.5*(tanh(-a(|x|-r))+1)*b + s + max(0, a_ex - a_le) */
+  double eta_a, eta_s;              /* 0.5*(tanh(-a*qdot.qdot - s)+1) ; a = 0.9*(1-1/2) */
+  double mount[MRF_MAX_ROBOTS][12]; /* 3x4 row-major [R|t] per robot (EXJ:107-118) */
+  double limits[MRF_DOF_MAX][2];    /* EXJ:97-105 */
+  int32_t sphere_link[MRF_MAX_SPHERES];     /* parent link number 1..8 */
+  double sphere_offset[MRF_MAX_SPHERES][3]; /* link-local xyz (SIM:188-245) */
+  double sphere_radius[MRF_MAX_SPHERES];
+  mrf_leaf_fn collision_geometry, collision_finsler;
+  mrf_leaf_fn plane_geometry, plane_finsler;
+  mrf_leaf_fn limit_geometry, limit_finsler;
+} mrf_config;
+
+typedef struct mrf_handle mrf_handle;
+
+/* Fill cfg with the reference's Panda defaults (leaf strings EXJ:87-89, limits EXJ:97-105,
+ * dt/mode PM:8,12, 8 link-origin spheres r=0.08 PM:23-26) for n_robots in {2,3} mounts
+ * (PM:83-105) or a ring of mounts otherwise.  Host-only, no device needed. */
+void mrf_default_config_panda(mrf_config* cfg, int32_t n_robots, int32_t horizon);
+/* Defaults of the 4-point-robot examples (example_pointmasses_static.py:102-129). */
+void mrf_default_config_planar3(mrf_config* cfg, int32_t n_robots);
+
+/* Validates cfg, selects the device (device_id >= 0) and uploads the immutable constants.
+ * There is no CPU path: without a usable HIP device this returns MRF_E_DEVICE. */
+int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out);
+void mrf_destroy(mrf_handle* h);
+const char* mrf_last_error(const mrf_handle* h);
+int mrf_abi_version(void);
+
+/* Replaces ParameterizedFabricPlanner.compute_action (EXJ:441,444; EXC:447,449; FPC:150-190).
+ *   q, qdot      [dof][rows]
+ *   params       [MRF_NPARAM][rows]
+ *   obst_x/v/a   [n_obst][3][rows]   obst_r [n_obst][rows]   (static obstacles: v = a = 0)
+ *   qddot_out    [dof][rows] (may be NULL)     action_out [dof][rows]
+ */
+int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
+                       int32_t n_obst, const void* obst_x, const void* obst_v, const void* obst_a,
+                       const void* obst_r, void* qddot_out, void* action_out, void* stream);
+
+/* Replaces ForwardFabricsPlanner.get_velocity_rollouts / rollouts_numerical (FPJ:190-249,298-423):
+ * the coupled N-robot, H-step joint-space rollout.  rows = n_scenarios * n_robots.
+ *   q0, qdot0 [dof][rows]   params [MRF_NPARAM][rows]
+ *   avg_vel_out [rows]                       mean squared joint velocity (FPJ:102-116)
+ *   traj_q, traj_qdot [H][dof][rows]         optional (NULL to skip), == q_N_fun / q_dot_N_fun
+ */
+int mrf_rollout(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* qdot0, const void* params,
+                void* avg_vel_out, void* traj_q, void* traj_qdot, void* stream);
+
+/* Replaces FabricsRollouts.get_velocity_rollouts / rollouts_numerical (FPC:347-489,538-563):
+ * per-row independent rollout, action-then-step, obstacles at constant Cartesian velocity. */
+int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,
+                          int32_t n_obst, const void* obst_x0, const void* obst_v, const void* obst_a,
+                          const void* obst_r, void* avg_vel_out, void* traj_q, void* traj_qdot, void* stream);
+
+/* Replaces the fk/jac/jac_dot helper evaluations (utils.py:16-54,87-119; FPJ:82-100; UFK:3-33):
+ * for every row the S configured spheres  x, v = J qdot, a = jdot_sign * Jdot qdot.
+ *   x_out, v_out, a_out [S][3][rows]  (v_out/a_out may be NULL) */
+int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot, void* x_out, void* v_out,
+                   void* a_out, void* stream);
+
+/* Robot-sharded rollout (one or a few robots per GPU).  One rollout step is
+ *   mrf_step_predict : q += dt*qdot for the owned robots; writes their spheres (x,v,a)
+ *   <all-gather of the sphere block across ranks -- done by the host over RCCL>
+ *   mrf_step_action  : fabric solve of the owned robots against all other robots' spheres;
+ *                      qdot := action; sumsq += |qdot|^2
+ * Owned rows are [n_scenarios][robot_count] with robot index robot_first + (row % robot_count).
+ *   sph_own  [robot_count][S][9][n_scenarios]   (x,v,a interleaved as 9 components)
+ *   sph_all  [n_robots  ][S][9][n_scenarios]
+ */
+int mrf_step_predict(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, void* q_io,
+                     const void* qdot, void* sph_own, void* stream);
+int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
+                    void* qdot_io, const void* params, const void* sph_all, void* sumsq_io, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRF_H_ */

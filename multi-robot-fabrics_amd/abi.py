@@ -1,0 +1,133 @@
+"""ctypes mirror of include/mrf.h and the loader of the HIP shared library.
+
+The product path has no CPU fallback: if csrc/libmrf_hip.so is missing or cannot be loaded,
+`load_library()` raises, and every planner / rollout class raises with it.
+"""
+import ctypes as C
+import os
+
+MRF_ABI_VERSION = 1
+MRF_MAX_ROBOTS = 16
+MRF_MAX_SPHERES = 32
+MRF_DOF_MAX = 7
+MRF_N_EGO = 6
+
+# per-row parameter vector (include/mrf.h)
+P_X_GOAL_0 = 0
+P_WEIGHT_GOAL_0 = 3
+P_ANGLE_GOAL_1 = 4
+P_X_GOAL_1 = 13
+P_WEIGHT_GOAL_1 = 16
+P_X_GOAL_2 = 17
+P_WEIGHT_GOAL_2 = 18
+P_CONSTRAINT_0 = 19
+P_RADIUS_BODY = 23
+NPARAM = 29
+
+MODEL_PANDA7, MODEL_PLANAR3 = 0, 1
+MODE_ACC, MODE_VEL = 0, 1
+F64, F32 = 0, 1
+FAMILY_POW, FAMILY_LOGISTIC = 0, 1
+GATE_NONE, GATE_NEG = 0, 1
+
+STATUS_TEXT = {0: "MRF_OK", -1: "MRF_E_ARG", -2: "MRF_E_CONFIG", -3: "MRF_E_DEVICE", -4: "MRF_E_LAUNCH"}
+
+
+class LeafFn(C.Structure):
+    _fields_ = [("family", C.c_int32), ("gate", C.c_int32), ("p", C.c_int32), ("reserved", C.c_int32),
+                ("k", C.c_double), ("c", C.c_double), ("s", C.c_double)]
+
+    def as_tuple(self):
+        return (self.family, self.gate, self.p, self.k, self.c, self.s)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("model", C.c_int32), ("scalar", C.c_int32), ("mode", C.c_int32),
+        ("n_robots", C.c_int32), ("n_spheres", C.c_int32), ("horizon", C.c_int32), ("dynamic", C.c_int32),
+        ("n_ego", C.c_int32), ("n_planes", C.c_int32), ("use_limits", C.c_int32), ("n_goals", C.c_int32),
+        ("plane_abs", C.c_int32), ("zero_small_action", C.c_int32), ("obst_dim", C.c_int32),
+        ("goal_estimate_mask", C.c_int32),
+        ("dt", C.c_double), ("eps", C.c_double), ("jdot_sign", C.c_double), ("goal_estimate_T", C.c_double),
+        ("base_mass", C.c_double),
+        ("attr_k", C.c_double), ("attr_alpha", C.c_double),
+        ("attr_mu", C.c_double), ("attr_ml", C.c_double), ("attr_a", C.c_double),
+        ("beta_a", C.c_double), ("beta_r", C.c_double), ("beta_b", C.c_double), ("beta_s", C.c_double),
+        ("eta_a", C.c_double), ("eta_s", C.c_double),
+        ("mount", (C.c_double * 12) * MRF_MAX_ROBOTS),
+        ("limits", (C.c_double * 2) * MRF_DOF_MAX),
+        ("sphere_link", C.c_int32 * MRF_MAX_SPHERES),
+        ("sphere_offset", (C.c_double * 3) * MRF_MAX_SPHERES),
+        ("sphere_radius", C.c_double * MRF_MAX_SPHERES),
+        ("collision_geometry", LeafFn), ("collision_finsler", LeafFn),
+        ("plane_geometry", LeafFn), ("plane_finsler", LeafFn),
+        ("limit_geometry", LeafFn), ("limit_finsler", LeafFn),
+    ]
+
+    def copy(self):
+        out = Config()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(Config))
+        return out
+
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
+
+EXPORTS = [
+    "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
+    "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_rollout", "mrf_rollout_cartesian",
+    "mrf_fk_spheres", "mrf_step_predict", "mrf_step_action",
+]
+
+_lib = None
+
+
+class MrfLibraryError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """Load csrc/libmrf_hip.so (built by __graft_entry__.build()).  Raises if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MrfLibraryError(
+            f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the fabric solve.")
+    lib = C.CDLL(p)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.mrf_default_config_panda.argtypes = [C.POINTER(Config), i32, i32]
+    lib.mrf_default_config_panda.restype = None
+    lib.mrf_default_config_planar3.argtypes = [C.POINTER(Config), i32]
+    lib.mrf_default_config_planar3.restype = None
+    lib.mrf_create.argtypes = [C.POINTER(Config), i32, C.POINTER(vp)]
+    lib.mrf_create.restype = C.c_int
+    lib.mrf_destroy.argtypes = [vp]
+    lib.mrf_destroy.restype = None
+    lib.mrf_last_error.argtypes = [vp]
+    lib.mrf_last_error.restype = C.c_char_p
+    lib.mrf_abi_version.argtypes = []
+    lib.mrf_abi_version.restype = C.c_int
+    lib.mrf_config_sizeof.argtypes = []
+    lib.mrf_config_sizeof.restype = C.c_int64
+    lib.mrf_compute_action.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_compute_action.restype = C.c_int
+    lib.mrf_rollout.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_rollout.restype = C.c_int
+    lib.mrf_rollout_cartesian.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_rollout_cartesian.restype = C.c_int
+    lib.mrf_fk_spheres.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.mrf_fk_spheres.restype = C.c_int
+    lib.mrf_step_predict.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
+    lib.mrf_step_predict.restype = C.c_int
+    lib.mrf_step_action.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mrf_step_action.restype = C.c_int
+    if lib.mrf_abi_version() != MRF_ABI_VERSION:
+        raise MrfLibraryError(f"ABI mismatch: library {lib.mrf_abi_version()} != python {MRF_ABI_VERSION}")
+    if lib.mrf_config_sizeof() != C.sizeof(Config):
+        raise MrfLibraryError(f"mrf_config size mismatch: C {lib.mrf_config_sizeof()} != ctypes {C.sizeof(Config)}")
+    if path is None:
+        _lib = lib
+    return lib
