@@ -121,6 +121,7 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out);
 void mrf_destroy(mrf_handle* h);
 const char* mrf_last_error(const mrf_handle* h);
 int mrf_abi_version(void);
+int64_t mrf_config_sizeof(void); /* sizeof(mrf_config) as compiled, for FFI layout checks */
 
 /* Replaces ParameterizedFabricPlanner.compute_action (EXJ:441,444; EXC:447,449; FPC:150-190).
  *   q, qdot      [dof][rows]

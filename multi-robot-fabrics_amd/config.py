@@ -39,8 +39,9 @@ Z_TABLE = 0.65                                                            # PM:8
 
 
 def mount_positions(n_robots):
-    """PM:83-105 for 2 and 3 robots; for other counts a build-defined ring (radius 0.6 around
-    (0.5, 0, z_table)), the robots facing the centre -- the reference defines no layout there."""
+    """PM:83-105 for 2 and 3 robots; for other counts a build-defined ring around (0.5, 0, z_table) of
+    radius max(0.75, 0.15 N) (neighbouring mounts ~0.9-1.0 m apart, like the reference's 1.0 m), the
+    robots facing the centre -- the reference defines no layout there."""
     if n_robots == 1:
         return [np.array([0.0, 0.0, Z_TABLE])], [0.0]
     if n_robots == 2:
@@ -49,7 +50,7 @@ def mount_positions(n_robots):
         return ([np.array([0.0, 0.0, Z_TABLE]), np.array([1.0, 0.0, Z_TABLE]), np.array([0.7, 0.6, Z_TABLE])],
                 [0.0, math.pi, math.pi])
     pos, yaw = [], []
-    rad = 0.6 * max(1.0, n_robots / 6.0)
+    rad = max(0.75, 0.15 * n_robots)
     for i in range(n_robots):
         ang = 2.0 * math.pi * i / n_robots
         pos.append(np.array([0.5 + rad * math.cos(ang), rad * math.sin(ang), Z_TABLE]))

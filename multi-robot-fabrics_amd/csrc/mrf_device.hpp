@@ -1,0 +1,701 @@
+// mrf_device.hpp -- device-side building blocks of the fabric solve for gfx950 (CDNA4).
+//
+// One thread owns one (scenario, robot) row.  Everything a row needs between the first load and the
+// last store lives in registers; the only memory traffic inside a rollout is the exchange of joint
+// state between the robots of one scenario (a per-wave LDS tile), so the kernels are VALU-bound by
+// construction (DESIGN.md "kernels").  No MFMA: the contractions are 3x3 / 3x7 / 7x7.
+//
+// What is computed (DESIGN.md "spec"):
+//   chain walk      : Panda forward kinematics with the URDF constants folded in (all joint axes local z,
+//                     roll in {0, +-pi/2}), plus the velocity and (qddot = 0) acceleration of every joint
+//                     origin by the classic outward recursion  -> x, v = J qd, Jdot qd
+//                     (replaces fk_fun / jac_fun / jac_dot_fun, reference utils.py:16-54)
+//   leaf folding    : every spherical-obstacle leaf of one ego point is rank-1 in that point's task space:
+//                     A += (m/R^2) n n^T,  b += n [ f/R + (m/R^2)(sign*kappa - n.a_o) ]
+//                     (the 3-stage pull geometry-map / dynamic-map / fk of `fabrics`, folded)
+//   pullback        : M_q += J^T A J, f_q += J^T (b + A c) once per ego point, J built column by column
+//                     as z_j x (p - o_j)
+//   solve           : LDL^T of the 7x7 (SPD: base 0.2 I + PSD leaf metrics), energization, damping
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/mrf.h"
+
+namespace mrf {
+
+constexpr int NG = 5;  // distinct ego collision points of a Panda: links 3, 4, 5(=6), 7, 8
+
+template <typename T>
+struct LeafFn {
+  int family, gate, p, pad;
+  T k, c, s;
+};
+
+template <typename T>
+struct DevCfg {
+  int model, mode, n_robots, n_spheres, horizon, dynamic, n_ego, n_planes;
+  int use_limits, n_goals, plane_abs, zero_small, obst_dim, goal_mask, pad0, pad1;
+  T dt, eps, jsign, goal_T, base_mass;
+  T attr_k, attr_alpha, attr_mu, attr_ml, attr_a;
+  T beta_a, beta_r, beta_b, beta_s, eta_a, eta_s;
+  T mount[MRF_MAX_ROBOTS][12];
+  T limits[MRF_DOF_MAX][2];
+  int sphere_link[MRF_MAX_SPHERES];
+  T sphere_off[MRF_MAX_SPHERES][3];
+  T sphere_r[MRF_MAX_SPHERES];
+  LeafFn<T> cg, cf, pg, pf, lg, lf;
+};
+
+// ------------------------------------------------------------------------------------ math wrappers
+__device__ __forceinline__ double m_sqrt(double x) { return ::sqrt(x); }
+__device__ __forceinline__ float m_sqrt(float x) { return ::sqrtf(x); }
+__device__ __forceinline__ double m_exp(double x) { return ::exp(x); }
+__device__ __forceinline__ float m_exp(float x) { return ::expf(x); }
+__device__ __forceinline__ double m_tanh(double x) { return ::tanh(x); }
+__device__ __forceinline__ float m_tanh(float x) { return ::tanhf(x); }
+__device__ __forceinline__ double m_abs(double x) { return ::fabs(x); }
+__device__ __forceinline__ float m_abs(float x) { return ::fabsf(x); }
+__device__ __forceinline__ double m_max(double a, double b) { return ::fmax(a, b); }
+__device__ __forceinline__ float m_max(float a, float b) { return ::fmaxf(a, b); }
+__device__ __forceinline__ void m_sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
+__device__ __forceinline__ void m_sincos(float x, float* s, float* c) { ::sincosf(x, s, c); }
+
+template <typename T>
+__device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T>
+__device__ __forceinline__ T dot3(const T* a, const T* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// x^p for a wave-uniform integer 0 <= p <= 16
+template <typename T>
+__device__ __forceinline__ T powi(T x, int p) {
+  T x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, r = T(1);
+  if (p & 1) r *= x;
+  if (p & 2) r *= x2;
+  if (p & 4) r *= x4;
+  if (p & 8) r *= x8;
+  if (p & 16) r *= x8 * x8;
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T gate_value(int gate, T xd) {
+  return gate == MRF_GATE_NONE ? T(1) : (xd < T(0) ? T(1) : (xd > T(0) ? T(0) : T(0.5)));
+}
+
+// coefficient in front of xdot^2 of a leaf string; ix = 1/x is shared between the two strings of a leaf
+template <typename T>
+__device__ __forceinline__ T leaf_coeff(const LeafFn<T>& f, T x, T ix, T xd) {
+  T g = gate_value<T>(f.gate, xd);
+  T v;
+  if (f.family == MRF_FAMILY_POW)
+    v = f.k * powi(ix, f.p);
+  else
+    v = f.k * (T(1) / (T(1) + f.c * m_exp(-f.s * x)) - T(1));
+  return v * g;
+}
+
+// metric m = d2L/dxd2 and force f = m*h of a scalar barrier leaf at (x, xd)
+template <typename T>
+__device__ __forceinline__ void scalar_leaf(const LeafFn<T>& geo, const LeafFn<T>& fin, T x, T xd, T& m, T& f) {
+  T ix = T(1) / x;
+  m = T(2) * leaf_coeff(fin, x, ix, xd);
+  f = m * leaf_coeff(geo, x, ix, xd) * xd * xd;
+}
+
+// ------------------------------------------------------------------------------------ Panda chain
+// panda_joint1..7 origins (URDF panda_with_finger.urdf:98-107,150-158,201-209,253-261,326-334,378-386,451-459)
+// and the fixed panda_joint8 (:461-465) as an eighth, non-moving "joint".
+__device__ constexpr double kPX[8] = {0.0, 0.0, 0.0, 0.0825, -0.0825, 0.0, 0.088, 0.0};
+__device__ constexpr double kPY[8] = {0.0, 0.0, -0.316, 0.0, 0.384, 0.0, 0.0, 0.0};
+__device__ constexpr double kPZ[8] = {0.333, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.107};
+__device__ constexpr int kROLL[8] = {0, -1, 1, 1, -1, 1, 1, 0};  // roll = k * pi/2
+
+template <typename T>
+struct PandaKin {
+  T o[7][3];   // origin of joint j == origin of panda_link(j+1)
+  T z[7][3];   // axis of joint j (world)
+  T vo[7][3];  // velocity of o[j]
+  T ao[7][3];  // d(J qd)/dq qd of o[j]  (true Jdot qd, no sign convention)
+  T p8[3], v8[3], a8[3];  // panda_link8 == panda_hand origin
+};
+
+// Unrolled walk of the own robot; all tables are compile-time so zero offsets and quarter-turn rolls fold away.
+template <typename T>
+__device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, const T (&cq)[7], const T (&sq)[7],
+                                               const T (&qd)[7], PandaKin<T>& K) {
+  T X[3] = {mount[0], mount[4], mount[8]}, Y[3] = {mount[1], mount[5], mount[9]}, Z[3] = {mount[2], mount[6], mount[10]};
+  T o[3] = {mount[3], mount[7], mount[11]};
+  T w[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)}, vo[3] = {T(0), T(0), T(0)}, ao[3] = {T(0), T(0), T(0)};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (kPX[j] != 0.0 || kPY[j] != 0.0 || kPZ[j] != 0.0) {
+      T r[3] = {T(0), T(0), T(0)};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (kPX[j] != 0.0) r[k] += T(kPX[j]) * X[k];
+        if (kPY[j] != 0.0) r[k] += T(kPY[j]) * Y[k];
+        if (kPZ[j] != 0.0) r[k] += T(kPZ[j]) * Z[k];
+      }
+      T wr[3], wwr[3], ar[3];
+      cross3(w, r, wr);
+      cross3(w, wr, wwr);
+      cross3(al, r, ar);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        o[k] += r[k];
+        vo[k] += wr[k];
+        ao[k] += ar[k] + wwr[k];
+      }
+    }
+    if (j == 7) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        K.p8[k] = o[k];
+        K.v8[k] = vo[k];
+        K.a8[k] = ao[k];
+      }
+      break;
+    }
+    if (kROLL[j] == 1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        T t = Y[k];
+        Y[k] = Z[k];
+        Z[k] = -t;
+      }
+    } else if (kROLL[j] == -1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        T t = Y[k];
+        Y[k] = -Z[k];
+        Z[k] = t;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      T xn = cq[j] * X[k] + sq[j] * Y[k];
+      T yn = cq[j] * Y[k] - sq[j] * X[k];
+      X[k] = xn;
+      Y[k] = yn;
+      K.o[j][k] = o[k];
+      K.z[j][k] = Z[k];
+      K.vo[j][k] = vo[k];
+      K.ao[j][k] = ao[k];
+    }
+    T wz[3];
+    cross3(w, Z, wz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      al[k] += qd[j] * wz[k];
+      w[k] += qd[j] * Z[k];
+    }
+  }
+}
+
+// Rolled walk of a robot whose spheres are wanted: emits (x, v, Jdot qd) of every configured sphere, in
+// table order, to `emit(s, x, v, a)`.  State is a handful of named vectors, so the loop over joints stays
+// rolled and the consumer is instantiated once.  get(j, c, s, qd) supplies cos q_j, sin q_j, qdot_j.
+template <typename T, typename Get, typename Emit>
+__device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T* __restrict__ mount, Get get,
+                                                   Emit emit) {
+  T X[3] = {mount[0], mount[4], mount[8]}, Y[3] = {mount[1], mount[5], mount[9]}, Z[3] = {mount[2], mount[6], mount[10]};
+  T o[3] = {mount[3], mount[7], mount[11]};
+  T w[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)}, vo[3] = {T(0), T(0), T(0)}, ao[3] = {T(0), T(0), T(0)};
+  int s = 0;
+  const int S = cfg.n_spheres;
+#pragma unroll 1
+  for (int j = 0; j < 8; ++j) {
+    T r[3];
+    const T px = T(kPX[j]), py = T(kPY[j]), pz = T(kPZ[j]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = px * X[k] + py * Y[k] + pz * Z[k];
+    {
+      T wr[3], wwr[3], ar[3];
+      cross3(w, r, wr);
+      cross3(w, wr, wwr);
+      cross3(al, r, ar);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        o[k] += r[k];
+        vo[k] += wr[k];
+        ao[k] += ar[k] + wwr[k];
+      }
+    }
+    if (j < 7) {
+      const int roll = kROLL[j];
+      if (roll != 0) {
+        const T sg = T(roll);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          T t = Y[k];
+          Y[k] = sg * Z[k];
+          Z[k] = -sg * t;
+        }
+      }
+      T c, sn, qdj;
+      get(j, c, sn, qdj);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        T xn = c * X[k] + sn * Y[k];
+        T yn = c * Y[k] - sn * X[k];
+        X[k] = xn;
+        Y[k] = yn;
+      }
+      T wz[3];
+      cross3(w, Z, wz);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        al[k] += qdj * wz[k];
+        w[k] += qdj * Z[k];
+      }
+    }
+    // spheres attached to panda_link(j+1): frame (X,Y,Z,o), angular state (w, al) of that link
+    while (s < S && cfg.sphere_link[s] == j + 1) {
+      T rr[3], x[3], v[3], a[3], wr[3], wwr[3], ar[3];
+      const T ox = cfg.sphere_off[s][0], oy = cfg.sphere_off[s][1], oz = cfg.sphere_off[s][2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rr[k] = ox * X[k] + oy * Y[k] + oz * Z[k];
+      cross3(w, rr, wr);
+      cross3(w, wr, wwr);
+      cross3(al, rr, ar);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        x[k] = o[k] + rr[k];
+        v[k] = vo[k] + wr[k];
+        a[k] = ao[k] + ar[k] + wwr[k];
+      }
+      emit(s, x, v, a);
+      ++s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ leaf folding
+template <typename T, int NP>
+struct EgoAcc {
+  T A[NP][6];  // xx xy xz yy yz zz
+  T b[NP][3];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) A[g][k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) b[g][k] = T(0);
+    }
+  }
+};
+
+template <typename T, int NP>
+struct EgoPts {
+  T p[NP][3];
+  T v[NP][3];
+  T rb[NP][2];  // body radius of the (up to two) links sharing this point
+  int nl[NP];   // number of links sharing the point (Panda: link5 and link6 share an origin)
+};
+
+// Add the spherical-obstacle leaves of all ego points against one obstacle sphere.
+// a_o is the obstacle's reference acceleration as the reference passes it (already sign-carrying).
+template <typename T, int NP>
+__device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* xo,
+                                                    const T* vo, const T* a_o, T ro, EgoAcc<T, NP>& acc) {
+  const bool planar = cfg.obst_dim == 2;
+#pragma unroll
+  for (int g = 0; g < NP; ++g) {
+    T dx[3] = {E.p[g][0] - xo[0], E.p[g][1] - xo[1], planar ? T(0) : E.p[g][2] - xo[2]};
+    T vr[3] = {E.v[g][0] - vo[0], E.v[g][1] - vo[1], planar ? T(0) : E.v[g][2] - vo[2]};
+    T d2 = dot3(dx, dx);
+    T d = m_sqrt(d2);
+    T id = T(1) / d;
+    T n[3] = {dx[0] * id, dx[1] * id, dx[2] * id};
+    T nv = dot3(n, vr);
+    T kap = (dot3(vr, vr) - nv * nv) * id;
+    T na = planar ? n[0] * a_o[0] + n[1] * a_o[1] : dot3(n, a_o);
+    T curv = cfg.jsign * kap - na;
+    T wM = T(0), wf = T(0);
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (l < E.nl[g]) {
+        T iR = T(1) / (ro + E.rb[g][l]);
+        T x = d * iR - T(1);
+        T xd = nv * iR;
+        T m, f;
+        scalar_leaf(cfg.cg, cfg.cf, x, xd, m, f);
+        T wm = m * iR * iR;
+        wM += wm;
+        wf += f * iR + wm * curv;
+      }
+    }
+    acc.A[g][0] += wM * n[0] * n[0];
+    acc.A[g][1] += wM * n[0] * n[1];
+    acc.A[g][2] += wM * n[0] * n[2];
+    acc.A[g][3] += wM * n[1] * n[1];
+    acc.A[g][4] += wM * n[1] * n[2];
+    acc.A[g][5] += wM * n[2] * n[2];
+    acc.b[g][0] += wf * n[0];
+    acc.b[g][1] += wf * n[1];
+    acc.b[g][2] += wf * n[2];
+  }
+}
+
+// plane-constraint leaves of all ego points:  x = |a.p + d|/|a| - r_body
+template <typename T, int NP>
+__device__ __forceinline__ void accumulate_plane(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* con,
+                                                 EgoAcc<T, NP>& acc) {
+  T ina = T(1) / m_sqrt(con[0] * con[0] + con[1] * con[1] + con[2] * con[2]);
+#pragma unroll
+  for (int g = 0; g < NP; ++g) {
+    T val = (con[0] * E.p[g][0] + con[1] * E.p[g][1] + con[2] * E.p[g][2] + con[3]) * ina;
+    T sg = T(1);
+    if (cfg.plane_abs) sg = val < T(0) ? T(-1) : (val > T(0) ? T(1) : T(0));
+    T n[3] = {sg * con[0] * ina, sg * con[1] * ina, sg * con[2] * ina};
+    T xd = dot3(n, E.v[g]);
+    T wM = T(0), wf = T(0);
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (l < E.nl[g]) {
+        T x = sg * val - E.rb[g][l];
+        T m, f;
+        scalar_leaf(cfg.pg, cfg.pf, x, xd, m, f);
+        wM += m;
+        wf += f;
+      }
+    }
+    acc.A[g][0] += wM * n[0] * n[0];
+    acc.A[g][1] += wM * n[0] * n[1];
+    acc.A[g][2] += wM * n[0] * n[2];
+    acc.A[g][3] += wM * n[1] * n[1];
+    acc.A[g][4] += wM * n[1] * n[2];
+    acc.A[g][5] += wM * n[2] * n[2];
+    acc.b[g][0] += wf * n[0];
+    acc.b[g][1] += wf * n[1];
+    acc.b[g][2] += wf * n[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------ configuration-space spec
+template <int N>
+__host__ __device__ constexpr int tri(int i, int j) {  // upper triangle, i <= j
+  return i * N - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <typename T, int N>
+struct QSpec {
+  T M[N * (N + 1) / 2];
+  T f[N];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int k = 0; k < N * (N + 1) / 2; ++k) M[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < N; ++k) f[k] = T(0);
+  }
+};
+
+// M_q += J^T A J ; f_q += J^T t  for a point with NC leading non-zero Jacobian columns J[:,j] = z_j x (p - o_j)
+template <typename T, int NC>
+__device__ __forceinline__ void pull_point(QSpec<T, 7>& S, const PandaKin<T>& K, const T* p, const T* A6, const T* t) {
+  T J[NC][3], AJ[NC][3];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    T r[3] = {p[0] - K.o[j][0], p[1] - K.o[j][1], p[2] - K.o[j][2]};
+    cross3(K.z[j], r, J[j]);
+    AJ[j][0] = A6[0] * J[j][0] + A6[1] * J[j][1] + A6[2] * J[j][2];
+    AJ[j][1] = A6[1] * J[j][0] + A6[3] * J[j][1] + A6[4] * J[j][2];
+    AJ[j][2] = A6[2] * J[j][0] + A6[4] * J[j][1] + A6[5] * J[j][2];
+    S.f[j] += dot3(J[j], t);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = i; j < NC; ++j) S.M[tri<7>(i, j)] += dot3(J[i], AJ[j]);
+}
+
+// LDL^T solve of (M + eps I) h = f, M symmetric positive definite, upper-triangle storage (copy is consumed)
+template <typename T, int N>
+__device__ __forceinline__ void ldl_solve(const QSpec<T, N>& S, T eps, T (&h)[N]) {
+  T L[N * (N + 1) / 2];  // strict upper part holds L^T, diagonal holds 1/d
+#pragma unroll
+  for (int k = 0; k < N * (N + 1) / 2; ++k) L[k] = S.M[k];
+  T dinv[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    T d = L[tri<N>(j, j)] + eps;
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[tri<N>(k, j)] * L[tri<N>(k, j)] * L[tri<N>(k, k)];
+    L[tri<N>(j, j)] = d;       // d_j
+    dinv[j] = T(1) / d;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      T v = L[tri<N>(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[tri<N>(k, i)] * L[tri<N>(k, j)] * L[tri<N>(k, k)];
+      L[tri<N>(j, i)] = v * dinv[j];  // L_ij
+    }
+  }
+  T y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    T v = S.f[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[tri<N>(k, i)] * y[k];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    T v = y[i] * dinv[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) v -= L[tri<N>(i, k)] * h[k];
+    h[i] = v;
+  }
+}
+
+// attractor leaf quantities on a task value x (dim D): metric scalar 2A and force 2A*grad(psi)
+template <typename T, int D>
+__device__ __forceinline__ void attractor(const DevCfg<T>& cfg, const T* x, T w, T& twoA, T* f, T& rnorm) {
+  T r2 = T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) r2 += x[k] * x[k];
+  T r = m_sqrt(r2);
+  rnorm = r;
+  T ar = cfg.attr_a * r;
+  twoA = T(2) * ((cfg.attr_mu - cfg.attr_ml) * m_exp(-ar * ar) + cfg.attr_ml);
+  // grad psi = w k tanh(alpha r) x/r ; 0 at r == 0 (build convention, DESIGN.md "deviations")
+  T g = r > T(0) ? w * cfg.attr_k * m_tanh(cfg.attr_alpha * r) / r : T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) f[k] = twoA * g * x[k];
+}
+
+// energization + damping + action; returns qddot and the action
+template <typename T, int N>
+__device__ __forceinline__ void finish(const DevCfg<T>& cfg, const T (&qd)[N], bool forced, T alpha_g, const T (&hg)[N],
+                                       const T (&hf)[N], T xpsi, T (&qdd)[N], T (&act)[N]) {
+  T qq = T(0);
+#pragma unroll
+  for (int j = 0; j < N; ++j) qq += qd[j] * qd[j];
+  if (!forced) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) qdd[j] = -hg[j] - alpha_g * qd[j];
+  } else {
+    T qh = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) qh += qd[j] * hf[j];
+    T alpha_f = -qh / (cfg.eps + qq);
+    T eta = T(0.5) * (m_tanh(-cfg.eta_a * qq - cfg.eta_s) + T(1));
+    T a_ex = eta * alpha_g + (T(1) - eta) * alpha_f;
+    T beta = T(0.5) * (m_tanh(-cfg.beta_a * (xpsi - cfg.beta_r)) + T(1)) * cfg.beta_b + cfg.beta_s +
+             m_max(T(0), alpha_g - a_ex);
+#pragma unroll
+    for (int j = 0; j < N; ++j) qdd[j] = -hf[j] - (a_ex + beta) * qd[j];
+  }
+  T nrm = T(0);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    act[j] = cfg.mode == MRF_MODE_VEL ? qd[j] + cfg.dt * qdd[j] : qdd[j];
+    nrm += act[j] * act[j];
+  }
+  if (cfg.zero_small && m_sqrt(nrm) < cfg.eps) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) act[j] = T(0);
+  }
+}
+
+// ------------------------------------------------------------------------------------ Panda row solve
+template <typename T>
+struct PandaRow {
+  T q[7], qd[7], cq[7], sq[7];
+  T prm[MRF_NPARAM];
+};
+
+template <typename T>
+__device__ __forceinline__ void panda_ego_points(const DevCfg<T>& cfg, const PandaKin<T>& K, const T* prm,
+                                                 EgoPts<T, NG>& E) {
+  constexpr int jo[4] = {2, 3, 4, 6};  // joint-origin index of links 3, 4, 5(=6), 7
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      E.p[g][k] = K.o[jo[g]][k];
+      E.v[g][k] = K.vo[jo[g]][k];
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    E.p[4][k] = K.p8[k];
+    E.v[4][k] = K.v8[k];
+  }
+  const T* rb = prm + MRF_P_RADIUS_BODY;  // links 3..8
+  E.rb[0][0] = rb[0]; E.rb[0][1] = T(0); E.nl[0] = 1;
+  E.rb[1][0] = rb[1]; E.rb[1][1] = T(0); E.nl[1] = 1;
+  E.rb[2][0] = rb[2]; E.rb[2][1] = rb[3]; E.nl[2] = 2;
+  E.rb[3][0] = rb[4]; E.rb[3][1] = T(0); E.nl[3] = 1;
+  E.rb[4][0] = rb[5]; E.rb[4][1] = T(0); E.nl[4] = 1;
+  (void)cfg;
+}
+
+// Everything after the obstacle loop: plane + pullbacks + limits + attractors + solves + damping.
+template <typename T>
+__device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const PandaRow<T>& R, const PandaKin<T>& K,
+                                                 const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc, T (&qdd)[7], T (&act)[7]) {
+  QSpec<T, 7> S;
+  S.zero();
+#pragma unroll
+  for (int j = 0; j < 7; ++j) S.M[tri<7>(j, j)] = cfg.base_mass;
+  if (cfg.n_ego > 0) {
+    if (cfg.n_planes > 0) accumulate_plane(cfg, E, R.prm + MRF_P_CONSTRAINT_0, acc);
+    constexpr int jo[4] = {2, 3, 4, 6};
+    // t = b + A c with c = jsign * Jdot qd of the point
+#define MRF_PULL(g, NC, pp, aa)                                                                \
+  {                                                                                            \
+    T c[3] = {cfg.jsign * (aa)[0], cfg.jsign * (aa)[1], cfg.jsign * (aa)[2]};                  \
+    T t[3] = {acc.b[g][0] + acc.A[g][0] * c[0] + acc.A[g][1] * c[1] + acc.A[g][2] * c[2],      \
+              acc.b[g][1] + acc.A[g][1] * c[0] + acc.A[g][3] * c[1] + acc.A[g][4] * c[2],      \
+              acc.b[g][2] + acc.A[g][2] * c[0] + acc.A[g][4] * c[1] + acc.A[g][5] * c[2]};     \
+    pull_point<T, NC>(S, K, pp, acc.A[g], t);                                                  \
+  }
+    MRF_PULL(0, 2, K.o[jo[0]], K.ao[jo[0]])
+    MRF_PULL(1, 3, K.o[jo[1]], K.ao[jo[1]])
+    MRF_PULL(2, 4, K.o[jo[2]], K.ao[jo[2]])
+    MRF_PULL(3, 6, K.o[jo[3]], K.ao[jo[3]])
+    MRF_PULL(4, 6, K.p8, K.a8)
+#undef MRF_PULL
+  }
+  if (cfg.use_limits) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      T m, f;
+      scalar_leaf(cfg.lg, cfg.lf, R.q[j] - cfg.limits[j][0], R.qd[j], m, f);
+      S.M[tri<7>(j, j)] += m;
+      S.f[j] += f;
+      scalar_leaf(cfg.lg, cfg.lf, cfg.limits[j][1] - R.q[j], -R.qd[j], m, f);
+      S.M[tri<7>(j, j)] += m;
+      S.f[j] -= f;
+    }
+  }
+  T hg[7], hf[7];
+  ldl_solve<T, 7>(S, cfg.eps, hg);
+  T qq = T(0), qh = T(0);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    qq += R.qd[j] * R.qd[j];
+    qh += R.qd[j] * hg[j];
+  }
+  T alpha_g = -qh / (cfg.eps + qq);
+  T xpsi = T(0);
+  const bool forced = cfg.n_goals > 0;
+  if (forced) {
+    // attractor 0: panda_hand position -> x_goal_0   (EXJ:32-41)
+    {
+      T x0[3] = {K.p8[0] - R.prm[MRF_P_X_GOAL_0], K.p8[1] - R.prm[MRF_P_X_GOAL_0 + 1], K.p8[2] - R.prm[MRF_P_X_GOAL_0 + 2]};
+      T twoA, f0[3];
+      attractor<T, 3>(cfg, x0, R.prm[MRF_P_WEIGHT_GOAL_0], twoA, f0, xpsi);
+      T A6[6] = {twoA, T(0), T(0), twoA, T(0), twoA};
+      T t[3] = {f0[0] + twoA * cfg.jsign * K.a8[0], f0[1] + twoA * cfg.jsign * K.a8[1], f0[2] + twoA * cfg.jsign * K.a8[2]};
+      pull_point<T, 6>(S, K, K.p8, A6, t);
+    }
+    if (cfg.n_goals > 1) {
+      // attractor 1: R (p_hand - p_link7) -> x_goal_1 ; p_hand - p_link7 = 0.107 z_6   (EXJ:42-52)
+      const T* Rm = R.prm + MRF_P_ANGLE_GOAL_1;
+      T d8[3] = {K.p8[0] - K.o[6][0], K.p8[1] - K.o[6][1], K.p8[2] - K.o[6][2]};
+      T da[3] = {K.a8[0] - K.ao[6][0], K.a8[1] - K.ao[6][1], K.a8[2] - K.ao[6][2]};
+      T x1[3], c1[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        x1[i] = Rm[3 * i] * d8[0] + Rm[3 * i + 1] * d8[1] + Rm[3 * i + 2] * d8[2] - R.prm[MRF_P_X_GOAL_1 + i];
+        c1[i] = cfg.jsign * (Rm[3 * i] * da[0] + Rm[3 * i + 1] * da[1] + Rm[3 * i + 2] * da[2]);
+      }
+      T twoA, f1[3], rn;
+      attractor<T, 3>(cfg, x1, R.prm[MRF_P_WEIGHT_GOAL_1], twoA, f1, rn);
+      T t[3] = {f1[0] + twoA * c1[0], f1[1] + twoA * c1[1], f1[2] + twoA * c1[2]};
+      T J[6][3];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        T cz[3];
+        cross3(K.z[j], d8, cz);  // d(p8 - o6)/dq_j
+#pragma unroll
+        for (int i = 0; i < 3; ++i) J[j][i] = Rm[3 * i] * cz[0] + Rm[3 * i + 1] * cz[1] + Rm[3 * i + 2] * cz[2];
+        S.f[j] += dot3(J[j], t);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) S.M[tri<7>(i, j)] += twoA * dot3(J[i], J[j]);
+    }
+    if (cfg.n_goals > 2) {
+      // attractor 2: joint index 6 -> x_goal_2   (EXJ:53-60)
+      T x2[1] = {R.q[6] - R.prm[MRF_P_X_GOAL_2]};
+      T twoA, f2[1], rn;
+      attractor<T, 1>(cfg, x2, R.prm[MRF_P_WEIGHT_GOAL_2], twoA, f2, rn);
+      S.M[tri<7>(6, 6)] += twoA;
+      S.f[6] += f2[0];
+    }
+    ldl_solve<T, 7>(S, cfg.eps, hf);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) hf[j] = hg[j];
+  }
+  finish<T, 7>(cfg, R.qd, forced, alpha_g, hg, hf, xpsi, qdd, act);
+}
+
+// ------------------------------------------------------------------------------------ planar point robot
+// pointRobot1.urdf:91-113: prismatic x (origin z 0.05), prismatic y, revolute theta; collision link base_link.
+template <typename T>
+struct PlanarRow {
+  T q[3], qd[3];
+  T prm[MRF_NPARAM];
+};
+
+template <typename T>
+__device__ __forceinline__ void planar_ego(const PlanarRow<T>& R, EgoPts<T, 1>& E) {
+  E.p[0][0] = R.q[0]; E.p[0][1] = R.q[1]; E.p[0][2] = T(0.05);
+  E.v[0][0] = R.qd[0]; E.v[0][1] = R.qd[1]; E.v[0][2] = T(0);
+  E.rb[0][0] = R.prm[MRF_P_RADIUS_BODY]; E.rb[0][1] = T(0); E.nl[0] = 1;
+}
+
+template <typename T>
+__device__ __forceinline__ void planar_finish_row(const DevCfg<T>& cfg, const PlanarRow<T>& R, EgoAcc<T, 1>& acc,
+                                                  T (&qdd)[3], T (&act)[3]) {
+  // J = [e_x e_y 0] (3x3, third column zero), Jdot = 0
+  QSpec<T, 3> S;
+  S.zero();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) S.M[tri<3>(j, j)] = cfg.base_mass;
+  if (cfg.n_ego > 0) {
+    S.M[tri<3>(0, 0)] += acc.A[0][0];
+    S.M[tri<3>(0, 1)] += acc.A[0][1];
+    S.M[tri<3>(1, 1)] += acc.A[0][3];
+    S.f[0] += acc.b[0][0];
+    S.f[1] += acc.b[0][1];
+  }
+  T hg[3], hf[3];
+  ldl_solve<T, 3>(S, cfg.eps, hg);
+  T qq = T(0), qh = T(0);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    qq += R.qd[j] * R.qd[j];
+    qh += R.qd[j] * hg[j];
+  }
+  T alpha_g = -qh / (cfg.eps + qq);
+  T xpsi = T(0);
+  const bool forced = cfg.n_goals > 0;
+  if (forced) {
+    T x0[2] = {R.q[0] - R.prm[MRF_P_X_GOAL_0], R.q[1] - R.prm[MRF_P_X_GOAL_0 + 1]};
+    T twoA, f0[2];
+    attractor<T, 2>(cfg, x0, R.prm[MRF_P_WEIGHT_GOAL_0], twoA, f0, xpsi);
+    S.M[tri<3>(0, 0)] += twoA;
+    S.M[tri<3>(1, 1)] += twoA;
+    S.f[0] += f0[0];
+    S.f[1] += f0[1];
+    ldl_solve<T, 3>(S, cfg.eps, hf);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) hf[j] = hg[j];
+  }
+  finish<T, 3>(cfg, R.qd, forced, alpha_g, hg, hf, xpsi, qdd, act);
+}
+
+}  // namespace mrf

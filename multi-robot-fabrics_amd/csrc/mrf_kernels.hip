@@ -1,0 +1,812 @@
+// mrf_kernels.hip -- gfx950 kernels and the C ABI of include/mrf.h.
+//
+// Kernels (all templated on the scalar type, one thread per (scenario, robot) row):
+//   k_action_panda / k_action_planar   batched compute_action                 (EXJ:441,444; pointmass :191-199)
+//   k_rollout_panda                    coupled joint-space Rollout Fabrics     (FPJ:190-249)
+//   k_rollout_cart_panda               Cartesian constant-velocity rollout     (FPC:421-458)
+//   k_fk_spheres_panda                 sphere x, v, jac_dot*qd                 (utils.py:16-54,87-119)
+//   k_step_predict / k_step_action     the two halves of one robot-sharded rollout step
+//
+// Layout: every array is component-major over rows (a[c*rows + row]) so that consecutive lanes touch
+// consecutive addresses on every load and store.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mrf_device.hpp"
+
+namespace mrf {
+
+// ---------------------------------------------------------------------------- row loads
+template <typename T>
+__device__ __forceinline__ void load_panda_row(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
+                                               const T* __restrict__ prm, PandaRow<T>& R) {
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    R.q[j] = q[j * rows + r];
+    R.qd[j] = qd[j * rows + r];
+  }
+#pragma unroll
+  for (int p = 0; p < MRF_NPARAM; ++p) R.prm[p] = prm[p * rows + r];
+}
+
+template <typename T>
+__device__ __forceinline__ void panda_trig(PandaRow<T>& R) {
+#pragma unroll
+  for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+}
+
+// ---------------------------------------------------------------------------- compute_action
+template <typename T>
+__global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+                                                       const T* __restrict__ q, const T* __restrict__ qd,
+                                                       const T* __restrict__ prm, int n_obst,
+                                                       const T* __restrict__ ox, const T* __restrict__ ov,
+                                                       const T* __restrict__ oa, const T* __restrict__ orad,
+                                                       T* __restrict__ qdd_out, T* __restrict__ act_out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const DevCfg<T>& cfg = *cfgp;
+  PandaRow<T> R;
+  load_panda_row(rows, r, q, qd, prm, R);
+  panda_trig(R);
+  PandaKin<T> K;
+  panda_walk_own<T>(cfg.mount[(int)(r % cfg.n_robots)], R.cq, R.sq, R.qd, K);
+  EgoPts<T, NG> E;
+  panda_ego_points(cfg, K, R.prm, E);
+  EgoAcc<T, NG> acc;
+  acc.zero();
+  if (cfg.n_ego > 0) {
+#pragma unroll 1
+    for (int m = 0; m < n_obst; ++m) {
+      T xo[3], vo[3], ao[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
+        xo[c] = ox[idx];
+        vo[c] = ov ? ov[idx] : T(0);
+        ao[c] = oa ? oa[idx] : T(0);
+      }
+      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], acc);
+    }
+  }
+  T qdd[7], act[7];
+  panda_finish_row(cfg, R, K, E, acc, qdd, act);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    if (qdd_out) qdd_out[j * rows + r] = qdd[j];
+    act_out[j * rows + r] = act[j];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+                                                        const T* __restrict__ q, const T* __restrict__ qd,
+                                                        const T* __restrict__ prm, int n_obst,
+                                                        const T* __restrict__ ox, const T* __restrict__ ov,
+                                                        const T* __restrict__ oa, const T* __restrict__ orad,
+                                                        T* __restrict__ qdd_out, T* __restrict__ act_out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const DevCfg<T>& cfg = *cfgp;
+  PlanarRow<T> R;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    R.q[j] = q[j * rows + r];
+    R.qd[j] = qd[j * rows + r];
+  }
+#pragma unroll
+  for (int p = 0; p < MRF_NPARAM; ++p) R.prm[p] = prm[p * rows + r];
+  EgoPts<T, 1> E;
+  planar_ego(R, E);
+  EgoAcc<T, 1> acc;
+  acc.zero();
+  if (cfg.n_ego > 0) {
+#pragma unroll 1
+    for (int m = 0; m < n_obst; ++m) {
+      T xo[3], vo[3], ao[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
+        xo[c] = ox[idx];
+        vo[c] = ov ? ov[idx] : T(0);
+        ao[c] = oa ? oa[idx] : T(0);
+      }
+      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], acc);
+    }
+  }
+  T qdd[3], act[3];
+  planar_finish_row(cfg, R, acc, qdd, act);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (qdd_out) qdd_out[j * rows + r] = qdd[j];
+    act_out[j * rows + r] = act[j];
+  }
+}
+
+// ---------------------------------------------------------------------------- coupled joint-space rollout
+// One wave per block.  Lanes are (scenario, robot) pairs with the N robots of a scenario adjacent, so the
+// exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
+// stays inside the wave: each lane publishes cos q, sin q, qdot of its 7 joints to a 21 x 64 LDS tile and
+// re-walks the other robots' chains from that tile, streaming their spheres straight into its leaf sums.
+template <typename T>
+__global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
+                                                       const T* __restrict__ q0, const T* __restrict__ qd0,
+                                                       const T* __restrict__ prm, T* __restrict__ avg_out,
+                                                       T* __restrict__ traj_q, T* __restrict__ traj_qd) {
+  __shared__ T xch[21 * 64];
+  const DevCfg<T>& cfg = *cfgp;
+  const int N = cfg.n_robots;
+  const int spw = 64 / N;  // scenarios per wave
+  const int lane = threadIdx.x;
+  int ls = lane / N;
+  const int li = lane - ls * N;
+  int64_t scen = (int64_t)blockIdx.x * spw + ls;
+  const bool active = ls < spw && scen < n_scen;
+  if (ls >= spw) ls = 0;  // idle tail lanes shadow the wave's first scenario (no stores)
+  if (scen >= n_scen || !active) scen = (int64_t)blockIdx.x * spw + ls;
+  if (scen >= n_scen) scen = n_scen - 1;
+  const int64_t rows = n_scen * N;
+  const int64_t row = scen * N + li;
+
+  PandaRow<T> R;
+  load_panda_row(rows, row, q0, qd0, prm, R);
+  const T* mount_own = cfg.mount[li];
+
+  if ((cfg.goal_mask >> li) & 1) {
+    // RF-CV: the goal of this robot is not communicated; use x_ee + T * v_ee (EXC:355-357)
+    panda_trig(R);
+    PandaKin<T> K0;
+    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R.prm[MRF_P_X_GOAL_0 + c] = K0.p8[c] + cfg.goal_T * K0.v8[c];
+  }
+
+  T sumsq = T(0);
+  const int H = cfg.horizon;
+#pragma unroll 1
+  for (int k = 0; k < H; ++k) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) R.q[j] += cfg.dt * R.qd[j];  // system_step 'vel' (FPJ:77-80)
+    panda_trig(R);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+      xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+      xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+    }
+    __syncthreads();
+    PandaKin<T> K;
+    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
+    EgoPts<T, NG> E;
+    panda_ego_points(cfg, K, R.prm, E);
+    EgoAcc<T, NG> acc;
+    acc.zero();
+    if (cfg.n_ego > 0) {
+#pragma unroll 1
+      for (int d = 1; d < N; ++d) {
+        int jr = li + d;
+        if (jr >= N) jr -= N;
+        const int src = ls * N + jr;
+        const T* mount_o = cfg.mount[jr];
+        panda_walk_spheres<T>(
+            cfg, mount_o,
+            [&](int j, T& c, T& s, T& qdj) {
+              c = xch[(3 * j + 0) * 64 + src];
+              s = xch[(3 * j + 1) * 64 + src];
+              qdj = xch[(3 * j + 2) * 64 + src];
+            },
+            [&](int s, const T* x, const T* v, const T* a) {
+              T vv[3], aa[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                vv[c] = cfg.dynamic ? v[c] : T(0);               // FPJ:215-220
+                aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);   // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
+              }
+              accumulate_obstacle(cfg, E, x, vv, aa, cfg.sphere_r[s], acc);
+            });
+      }
+    }
+    T qdd[7], act[7];
+    panda_finish_row(cfg, R, K, E, acc, qdd, act);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      R.qd[j] = act[j];  // FPJ:233
+      sumsq += act[j] * act[j];
+    }
+    if (active && traj_q) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) traj_q[((int64_t)k * 7 + j) * rows + row] = R.q[j];
+    }
+    if (active && traj_qd) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) traj_qd[((int64_t)k * 7 + j) * rows + row] = R.qd[j];
+    }
+  }
+  if (active) avg_out[row] = sumsq / (T)(H * 7);  // FPJ:102-116
+}
+
+// ---------------------------------------------------------------------------- Cartesian rollout
+template <typename T>
+__global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+                                                             const T* __restrict__ q0, const T* __restrict__ qd0,
+                                                             const T* __restrict__ prm, int n_obst,
+                                                             const T* __restrict__ ox0, const T* __restrict__ ov,
+                                                             const T* __restrict__ oa, const T* __restrict__ orad,
+                                                             T* __restrict__ avg_out, T* __restrict__ traj_q,
+                                                             T* __restrict__ traj_qd) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const DevCfg<T>& cfg = *cfgp;
+  PandaRow<T> R;
+  load_panda_row(rows, r, q0, qd0, prm, R);
+  const T* mount_own = cfg.mount[(int)(r % cfg.n_robots)];
+  T sumsq = T(0);
+  T tk = T(0);  // elapsed obstacle time k*dt
+  const int H = cfg.horizon;
+#pragma unroll 1
+  for (int k = 0; k < H; ++k) {
+    panda_trig(R);
+    PandaKin<T> K;
+    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
+    EgoPts<T, NG> E;
+    panda_ego_points(cfg, K, R.prm, E);
+    EgoAcc<T, NG> acc;
+    acc.zero();
+    if (cfg.n_ego > 0) {
+#pragma unroll 1
+      for (int m = 0; m < n_obst; ++m) {
+        T xo[3], vo[3], ao[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
+          vo[c] = ov[idx];
+          xo[c] = ox0[idx] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
+          ao[c] = oa ? oa[idx] : T(0);
+        }
+        accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], acc);
+      }
+    }
+    T qdd[7], act[7];
+    panda_finish_row(cfg, R, K, E, acc, qdd, act);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (cfg.mode == MRF_MODE_VEL) {
+        R.qd[j] = act[j];
+        R.q[j] += cfg.dt * R.qd[j];
+      } else {
+        R.q[j] += cfg.dt * R.qd[j] + T(0.5) * cfg.dt * cfg.dt * act[j];
+        R.qd[j] += cfg.dt * act[j];
+      }
+      sumsq += R.qd[j] * R.qd[j];
+    }
+    if (traj_q) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) traj_q[((int64_t)k * 7 + j) * rows + r] = R.q[j];
+    }
+    if (traj_qd) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) traj_qd[((int64_t)k * 7 + j) * rows + r] = R.qd[j];
+    }
+    tk += cfg.dt;
+  }
+  avg_out[r] = sumsq / (T)(H * 7);
+}
+
+// ---------------------------------------------------------------------------- sphere kinematics
+template <typename T>
+__global__ __launch_bounds__(64) void k_fk_spheres_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+                                                          const T* __restrict__ q, const T* __restrict__ qd,
+                                                          T* __restrict__ x_out, T* __restrict__ v_out,
+                                                          T* __restrict__ a_out) {
+  __shared__ T xch[21 * 64];
+  const DevCfg<T>& cfg = *cfgp;
+  const int lane = threadIdx.x;
+  int64_t r = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = r < rows;
+  if (!active) r = rows - 1;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    T s, c;
+    m_sincos(q[j * rows + r], &s, &c);
+    xch[(3 * j + 0) * 64 + lane] = c;
+    xch[(3 * j + 1) * 64 + lane] = s;
+    xch[(3 * j + 2) * 64 + lane] = qd ? qd[j * rows + r] : T(0);
+  }
+  __syncthreads();
+  panda_walk_spheres<T>(
+      cfg, cfg.mount[(int)(r % cfg.n_robots)],
+      [&](int j, T& c, T& s, T& qdj) {
+        c = xch[(3 * j + 0) * 64 + lane];
+        s = xch[(3 * j + 1) * 64 + lane];
+        qdj = xch[(3 * j + 2) * 64 + lane];
+      },
+      [&](int s, const T* x, const T* v, const T* a) {
+        if (!active) return;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int64_t idx = (int64_t)(s * 3 + c) * rows + r;
+          x_out[idx] = x[c];
+          if (v_out) v_out[idx] = v[c];
+          if (a_out) a_out[idx] = cfg.jsign * a[c];
+        }
+      });
+}
+
+// ---------------------------------------------------------------------------- robot-sharded rollout step
+// predict: q += dt*qdot for the owned robots, publish their spheres as [robot][S][9][B].
+template <typename T>
+__global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
+                                                      int robot_count, T* __restrict__ q_io, const T* __restrict__ qd,
+                                                      T* __restrict__ sph_own) {
+  __shared__ T xch[21 * 64];
+  const DevCfg<T>& cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int64_t rows = n_scen * robot_count;
+  int64_t r = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = r < rows;
+  if (!active) r = rows - 1;
+  const int64_t scen = r / robot_count;
+  const int lr = (int)(r - scen * robot_count);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const T qdj = qd[j * rows + r];
+    const T qj = q_io[j * rows + r] + cfg.dt * qdj;
+    if (active) q_io[j * rows + r] = qj;
+    T s, c;
+    m_sincos(qj, &s, &c);
+    xch[(3 * j + 0) * 64 + lane] = c;
+    xch[(3 * j + 1) * 64 + lane] = s;
+    xch[(3 * j + 2) * 64 + lane] = qdj;
+  }
+  __syncthreads();
+  const int S = cfg.n_spheres;
+  panda_walk_spheres<T>(
+      cfg, cfg.mount[robot_first + lr],
+      [&](int j, T& c, T& s, T& qdj) {
+        c = xch[(3 * j + 0) * 64 + lane];
+        s = xch[(3 * j + 1) * 64 + lane];
+        qdj = xch[(3 * j + 2) * 64 + lane];
+      },
+      [&](int s, const T* x, const T* v, const T* a) {
+        if (!active) return;
+        const int64_t base = ((int64_t)(lr * S + s) * 9) * n_scen + scen;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          sph_own[base + (int64_t)c * n_scen] = x[c];
+          sph_own[base + (int64_t)(3 + c) * n_scen] = v[c];
+          sph_own[base + (int64_t)(6 + c) * n_scen] = cfg.jsign * a[c];
+        }
+      });
+}
+
+// action: fabric solve of the owned robots against every other robot's published spheres.
+template <typename T>
+__global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
+                                                      int robot_count, const T* __restrict__ q, T* __restrict__ qd_io,
+                                                      const T* __restrict__ prm, const T* __restrict__ sph_all,
+                                                      T* __restrict__ sumsq_io) {
+  const DevCfg<T>& cfg = *cfgp;
+  const int64_t rows = n_scen * robot_count;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t scen = r / robot_count;
+  const int lr = (int)(r - scen * robot_count);
+  const int me = robot_first + lr;
+  PandaRow<T> R;
+  load_panda_row(rows, r, q, qd_io, prm, R);
+  panda_trig(R);
+  PandaKin<T> K;
+  panda_walk_own<T>(cfg.mount[me], R.cq, R.sq, R.qd, K);
+  EgoPts<T, NG> E;
+  panda_ego_points(cfg, K, R.prm, E);
+  EgoAcc<T, NG> acc;
+  acc.zero();
+  const int N = cfg.n_robots, S = cfg.n_spheres;
+  if (cfg.n_ego > 0) {
+#pragma unroll 1
+    for (int d = 1; d < N; ++d) {
+      int jr = me + d;
+      if (jr >= N) jr -= N;
+#pragma unroll 1
+      for (int s = 0; s < S; ++s) {
+        const int64_t base = ((int64_t)(jr * S + s) * 9) * n_scen + scen;
+        T x[3], v[3], a[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          x[c] = sph_all[base + (int64_t)c * n_scen];
+          v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
+          a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
+        }
+        accumulate_obstacle(cfg, E, x, v, a, cfg.sphere_r[s], acc);
+      }
+    }
+  }
+  T qdd[7], act[7];
+  panda_finish_row(cfg, R, K, E, acc, qdd, act);
+  T ss = T(0);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    qd_io[j * rows + r] = act[j];
+    ss += act[j] * act[j];
+  }
+  sumsq_io[r] += ss;
+}
+
+}  // namespace mrf
+
+// ================================================================================ host side / C ABI
+struct mrf_handle {
+  mrf_config cfg;
+  int device;
+  void* dcfg;  // DevCfg<double> or DevCfg<float> on the device
+  std::string err;
+};
+
+namespace {
+
+template <typename T>
+void to_dev_leaf(const mrf_leaf_fn& s, mrf::LeafFn<T>& d) {
+  d.family = s.family;
+  d.gate = s.gate;
+  d.p = s.p;
+  d.pad = 0;
+  d.k = (T)s.k;
+  d.c = (T)s.c;
+  d.s = (T)s.s;
+}
+
+template <typename T>
+void to_dev_cfg(const mrf_config& c, mrf::DevCfg<T>& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.model = c.model; d.mode = c.mode; d.n_robots = c.n_robots; d.n_spheres = c.n_spheres;
+  d.horizon = c.horizon; d.dynamic = c.dynamic; d.n_ego = c.n_ego; d.n_planes = c.n_planes;
+  d.use_limits = c.use_limits; d.n_goals = c.n_goals; d.plane_abs = c.plane_abs;
+  d.zero_small = c.zero_small_action; d.obst_dim = c.obst_dim; d.goal_mask = c.goal_estimate_mask;
+  d.dt = (T)c.dt; d.eps = (T)c.eps; d.jsign = (T)c.jdot_sign; d.goal_T = (T)c.goal_estimate_T;
+  d.base_mass = (T)c.base_mass;
+  d.attr_k = (T)c.attr_k; d.attr_alpha = (T)c.attr_alpha; d.attr_mu = (T)c.attr_mu; d.attr_ml = (T)c.attr_ml;
+  d.attr_a = (T)c.attr_a;
+  d.beta_a = (T)c.beta_a; d.beta_r = (T)c.beta_r; d.beta_b = (T)c.beta_b; d.beta_s = (T)c.beta_s;
+  d.eta_a = (T)c.eta_a; d.eta_s = (T)c.eta_s;
+  for (int i = 0; i < MRF_MAX_ROBOTS; ++i)
+    for (int k = 0; k < 12; ++k) d.mount[i][k] = (T)c.mount[i][k];
+  for (int j = 0; j < MRF_DOF_MAX; ++j) {
+    d.limits[j][0] = (T)c.limits[j][0];
+    d.limits[j][1] = (T)c.limits[j][1];
+  }
+  for (int s = 0; s < MRF_MAX_SPHERES; ++s) {
+    d.sphere_link[s] = c.sphere_link[s];
+    for (int k = 0; k < 3; ++k) d.sphere_off[s][k] = (T)c.sphere_offset[s][k];
+    d.sphere_r[s] = (T)c.sphere_radius[s];
+  }
+  to_dev_leaf(c.collision_geometry, d.cg); to_dev_leaf(c.collision_finsler, d.cf);
+  to_dev_leaf(c.plane_geometry, d.pg);     to_dev_leaf(c.plane_finsler, d.pf);
+  to_dev_leaf(c.limit_geometry, d.lg);     to_dev_leaf(c.limit_finsler, d.lf);
+}
+
+void set_leaf(mrf_leaf_fn& f, int family, int gate, int p, double k, double c, double s) {
+  f.family = family; f.gate = gate; f.p = p; f.reserved = 0; f.k = k; f.c = c; f.s = s;
+}
+
+void common_defaults(mrf_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  c->abi_version = MRF_ABI_VERSION;
+  c->scalar = MRF_F64;
+  c->eps = 1e-6;
+  c->jdot_sign = -1.0;
+  c->goal_estimate_T = 20 * 0.01;
+  c->base_mass = 0.2;
+  c->attr_k = 5.0; c->attr_alpha = 10.0; c->attr_mu = 2.0; c->attr_ml = 0.3; c->attr_a = 0.75;
+  c->beta_a = 0.5; c->beta_r = 0.02; c->beta_b = 6.5; c->beta_s = 0.01;
+  c->eta_a = 0.9 * (1.0 - 0.5); c->eta_s = 0.5;
+  c->plane_abs = 1;
+  c->zero_small_action = 1;
+  c->dt = 0.01;
+  // library defaults (recalled, overridable): limits and plane finsler
+  set_leaf(c->limit_geometry, MRF_FAMILY_POW, MRF_GATE_NONE, 1, -0.1, 0, 0);
+  set_leaf(c->limit_finsler, MRF_FAMILY_POW, MRF_GATE_NEG, 1, 0.1, 0, 0);
+  set_leaf(c->plane_finsler, MRF_FAMILY_POW, MRF_GATE_NEG, 1, 0.1, 0, 0);
+}
+
+int fail(mrf_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+int check_hip(mrf_handle* h, hipError_t e, const char* what) {
+  if (e == hipSuccess) return MRF_OK;
+  return fail(h, MRF_E_LAUNCH, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+std::string validate(const mrf_config& c) {
+  if (c.abi_version != MRF_ABI_VERSION) return "abi_version mismatch";
+  if (c.model != MRF_MODEL_PANDA7 && c.model != MRF_MODEL_PLANAR3) return "unknown model";
+  if (c.scalar != MRF_F64 && c.scalar != MRF_F32) return "unknown scalar type";
+  if (c.mode != MRF_MODE_ACC && c.mode != MRF_MODE_VEL) return "unknown mode";
+  if (c.n_robots < 1 || c.n_robots > MRF_MAX_ROBOTS) return "n_robots out of range";
+  if (c.n_spheres < 0 || c.n_spheres > MRF_MAX_SPHERES) return "n_spheres out of range";
+  if (c.horizon < 1) return "horizon must be >= 1";
+  if (c.model == MRF_MODEL_PANDA7 && c.n_ego != 0 && c.n_ego != MRF_N_EGO) return "panda n_ego must be 0 or 6";
+  if (c.model == MRF_MODEL_PLANAR3 && c.n_ego != 0 && c.n_ego != 1) return "planar3 n_ego must be 0 or 1";
+  if (c.n_planes < 0 || c.n_planes > 1) return "n_planes must be 0 or 1";
+  if (c.model == MRF_MODEL_PANDA7 && (c.n_goals < 0 || c.n_goals > 3)) return "panda n_goals must be 0..3";
+  if (c.model == MRF_MODEL_PLANAR3 && (c.n_goals < 0 || c.n_goals > 1)) return "planar3 n_goals must be 0..1";
+  if (c.obst_dim != 2 && c.obst_dim != 3) return "obst_dim must be 2 or 3";
+  if (!(c.dt > 0) || !(c.eps > 0)) return "dt and eps must be positive";
+  int prev = 0;
+  for (int s = 0; s < c.n_spheres; ++s) {
+    int L = c.sphere_link[s];
+    if (L < 1 || L > 8) return "sphere_link must be in 1..8";
+    if (L < prev) return "sphere table must be sorted by link number";
+    prev = L;
+  }
+  const mrf_leaf_fn* fns[6] = {&c.collision_geometry, &c.collision_finsler, &c.plane_geometry,
+                               &c.plane_finsler, &c.limit_geometry, &c.limit_finsler};
+  for (const mrf_leaf_fn* f : fns) {
+    if (f->family != MRF_FAMILY_POW && f->family != MRF_FAMILY_LOGISTIC) return "unknown leaf family";
+    if (f->gate != MRF_GATE_NONE && f->gate != MRF_GATE_NEG) return "unknown leaf gate";
+    if (f->p < 0 || f->p > 16) return "leaf exponent p must be in 0..16";
+  }
+  return "";
+}
+
+template <typename K, typename... Args>
+int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+  hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+  return check_hip(h, hipGetLastError(), "kernel launch");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrf_abi_version(void) { return MRF_ABI_VERSION; }
+int64_t mrf_config_sizeof(void) { return (int64_t)sizeof(mrf_config); }
+
+void mrf_default_config_panda(mrf_config* c, int32_t n_robots, int32_t horizon) {
+  common_defaults(c);
+  c->model = MRF_MODEL_PANDA7;
+  c->mode = MRF_MODE_VEL;  // parameters_manipulators.py:12
+  c->n_robots = n_robots;
+  c->horizon = horizon;
+  c->dynamic = 1;
+  c->n_ego = MRF_N_EGO;
+  c->n_planes = 1;
+  c->use_limits = 1;
+  c->n_goals = 3;
+  c->obst_dim = 3;
+  const double kPi = 3.14159265358979323846;
+  for (int i = 0; i < n_robots && i < MRF_MAX_ROBOTS; ++i) {
+    double px, py, yaw;
+    if (n_robots <= 3) {  // parameters_manipulators.py:83-105,138-150
+      const double P[3][2] = {{0.0, 0.0}, {1.0, 0.0}, {0.7, 0.6}};
+      px = P[i][0]; py = P[i][1]; yaw = i == 0 ? 0.0 : kPi;
+    } else {              // build-defined ring (the reference defines no layout for N > 3)
+      double rad = 0.15 * n_robots > 0.75 ? 0.15 * n_robots : 0.75, ang = 2.0 * kPi * i / n_robots;
+      px = 0.5 + rad * std::cos(ang); py = rad * std::sin(ang); yaw = ang + kPi;
+    }
+    double cy = std::cos(yaw), sy = std::sin(yaw);
+    double M[12] = {cy, -sy, 0, px, sy, cy, 0, py, 0, 0, 1, 0.65};
+    std::memcpy(c->mount[i], M, sizeof(M));
+  }
+  const double lim[7][2] = {{-2.8973, 2.8973}, {-1.7628, 1.7628}, {-2.8973, 2.8973}, {-3.0718, -0.0698},
+                            {-2.8973, 2.8973}, {-0.0175, 3.7525}, {-2.8973, 2.8973}};  // EXJ:97-105
+  std::memcpy(c->limits, lim, sizeof(lim));
+  c->n_spheres = 8;  // link origins 1..8, radius 0.08 (PM:23-26)
+  for (int s = 0; s < 8; ++s) {
+    c->sphere_link[s] = s + 1;
+    c->sphere_radius[s] = 0.08;
+  }
+  set_leaf(c->collision_geometry, MRF_FAMILY_POW, MRF_GATE_NONE, 4, -0.5, 0, 0);  // EXJ:88
+  set_leaf(c->collision_finsler, MRF_FAMILY_POW, MRF_GATE_NONE, 4, 0.01, 0, 0);   // EXJ:89
+  set_leaf(c->plane_geometry, MRF_FAMILY_LOGISTIC, MRF_GATE_NONE, 0, 10.0, 1.0, 10.0);  // EXJ:87
+}
+
+void mrf_default_config_planar3(mrf_config* c, int32_t n_robots) {
+  common_defaults(c);
+  c->model = MRF_MODEL_PLANAR3;
+  c->mode = MRF_MODE_ACC;  // concretize() default, pointmass :128
+  c->n_robots = n_robots;
+  c->horizon = 1;
+  c->dynamic = 1;
+  c->n_ego = 1;
+  c->n_planes = 0;
+  c->use_limits = 0;
+  c->n_goals = 1;
+  c->obst_dim = 3;
+  for (int i = 0; i < n_robots && i < MRF_MAX_ROBOTS; ++i) {
+    double M[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    std::memcpy(c->mount[i], M, sizeof(M));
+  }
+  c->n_spheres = 1;
+  c->sphere_link[0] = 1;
+  c->sphere_radius[0] = 0.2;
+  set_leaf(c->collision_geometry, MRF_FAMILY_POW, MRF_GATE_NONE, 1, -2.0, 0, 0);  // pointmass :106
+  set_leaf(c->collision_finsler, MRF_FAMILY_POW, MRF_GATE_NEG, 2, 1.0, 0, 0);     // pointmass :107
+  set_leaf(c->plane_geometry, MRF_FAMILY_POW, MRF_GATE_NEG, 5, -0.5, 0, 0);
+}
+
+int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
+  if (!cfg || !out) return MRF_E_ARG;
+  *out = nullptr;
+  mrf_handle* h = new (std::nothrow) mrf_handle();
+  if (!h) return MRF_E_ARG;
+  h->cfg = *cfg;
+  h->device = device_id;
+  h->dcfg = nullptr;
+  *out = h;  // returned even on failure so that mrf_last_error() can be read; caller destroys it
+  std::string v = validate(*cfg);
+  if (!v.empty()) return fail(h, MRF_E_CONFIG, "invalid mrf_config: " + v);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(h, MRF_E_DEVICE, "no HIP device available (there is no CPU path)");
+  if (device_id < 0 || device_id >= ndev) return fail(h, MRF_E_DEVICE, "device_id out of range");
+  if (hipSetDevice(device_id) != hipSuccess) return fail(h, MRF_E_DEVICE, "hipSetDevice failed");
+  hipError_t e;
+  if (cfg->scalar == MRF_F64) {
+    mrf::DevCfg<double> d;
+    to_dev_cfg(*cfg, d);
+    e = hipMalloc(&h->dcfg, sizeof(d));
+    if (e == hipSuccess) e = hipMemcpy(h->dcfg, &d, sizeof(d), hipMemcpyHostToDevice);
+  } else {
+    mrf::DevCfg<float> d;
+    to_dev_cfg(*cfg, d);
+    e = hipMalloc(&h->dcfg, sizeof(d));
+    if (e == hipSuccess) e = hipMemcpy(h->dcfg, &d, sizeof(d), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) return fail(h, MRF_E_DEVICE, std::string("config upload: ") + hipGetErrorString(e));
+  return MRF_OK;
+}
+
+void mrf_destroy(mrf_handle* h) {
+  if (!h) return;
+  if (h->dcfg) (void)hipFree(h->dcfg);
+  delete h;
+}
+
+const char* mrf_last_error(const mrf_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+#define MRF_CHECK_READY(h)                              \
+  if (!(h)) return MRF_E_ARG;                           \
+  if (!(h)->dcfg) return fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)");
+
+int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
+                       int32_t n_obst, const void* ox, const void* ov, const void* oa, const void* orad,
+                       void* qddot_out, void* action_out, void* stream) {
+  MRF_CHECK_READY(h);
+  if (rows == 0) return MRF_OK;  // empty batch: nothing to read or write, pointers may be NULL
+  if (rows < 0 || n_obst < 0 || !q || !qdot || !params || !action_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  if (n_obst > 0 && (!ox || !orad)) return fail(h, MRF_E_ARG, "obstacle arrays missing");
+  if (rows == 0) return MRF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(256), grid((unsigned)((rows + 255) / 256));
+  const bool panda = h->cfg.model == MRF_MODEL_PANDA7;
+  if (h->cfg.scalar == MRF_F64) {
+    using T = double;
+    auto k = panda ? mrf::k_action_panda<T> : mrf::k_action_planar<T>;
+    return launch(h, k, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
+                  (const T*)params, (int)n_obst, (const T*)ox, (const T*)ov, (const T*)oa, (const T*)orad,
+                  (T*)qddot_out, (T*)action_out);
+  }
+  using T = float;
+  auto k = panda ? mrf::k_action_panda<T> : mrf::k_action_planar<T>;
+  return launch(h, k, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
+                (const T*)params, (int)n_obst, (const T*)ox, (const T*)ov, (const T*)oa, (const T*)orad,
+                (T*)qddot_out, (T*)action_out);
+}
+
+int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
+                void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "rollouts are defined for the panda7 model only");
+  if (h->cfg.mode != MRF_MODE_VEL)
+    return fail(h, MRF_E_CONFIG, "joint-space rollout is defined for mode 'vel' only (reference FPJ:233)");
+  if (h->cfg.n_robots > 64) return fail(h, MRF_E_CONFIG, "n_robots > 64");
+  if (n_scen == 0) return MRF_OK;
+  if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int spw = 64 / h->cfg.n_robots;
+  dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+  if (h->cfg.scalar == MRF_F64) {
+    using T = double;
+    return launch(h, mrf::k_rollout_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0,
+                  (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  }
+  using T = float;
+  return launch(h, mrf::k_rollout_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0,
+                (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+}
+
+int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,
+                          int32_t n_obst, const void* ox0, const void* ov, const void* oa, const void* orad,
+                          void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "rollouts are defined for the panda7 model only");
+  if (rows == 0) return MRF_OK;
+  if (rows < 0 || n_obst < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  if (n_obst > 0 && (!ox0 || !ov || !orad)) return fail(h, MRF_E_ARG, "obstacle arrays missing");
+  if (rows == 0) return MRF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(256), grid((unsigned)((rows + 255) / 256));
+  if (h->cfg.scalar == MRF_F64) {
+    using T = double;
+    return launch(h, mrf::k_rollout_cart_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0,
+                  (const T*)qdot0, (const T*)params, (int)n_obst, (const T*)ox0, (const T*)ov, (const T*)oa,
+                  (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  }
+  using T = float;
+  return launch(h, mrf::k_rollout_cart_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0,
+                (const T*)qdot0, (const T*)params, (int)n_obst, (const T*)ox0, (const T*)ov, (const T*)oa,
+                (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+}
+
+int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot, void* x_out, void* v_out,
+                   void* a_out, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "fk_spheres is defined for the panda7 model only");
+  if (rows == 0) return MRF_OK;
+  if (rows < 0 || !q || !x_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  if ((v_out || a_out) && !qdot) return fail(h, MRF_E_ARG, "qdot required for v/a");
+  if (rows == 0) return MRF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(64), grid((unsigned)((rows + 63) / 64));
+  if (h->cfg.scalar == MRF_F64) {
+    using T = double;
+    return launch(h, mrf::k_fk_spheres_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
+                  (const T*)qdot, (T*)x_out, (T*)v_out, (T*)a_out);
+  }
+  using T = float;
+  return launch(h, mrf::k_fk_spheres_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
+                (const T*)qdot, (T*)x_out, (T*)v_out, (T*)a_out);
+}
+
+int mrf_step_predict(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, void* q_io,
+                     const void* qdot, void* sph_own, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7 || h->cfg.mode != MRF_MODE_VEL)
+    return fail(h, MRF_E_CONFIG, "sharded rollout needs the panda7 model in mode 'vel'");
+  if (n_scen < 0 || robot_first < 0 || robot_count < 1 || robot_first + robot_count > h->cfg.n_robots || !q_io ||
+      !qdot || !sph_own)
+    return fail(h, MRF_E_ARG, "bad argument");
+  if (n_scen == 0) return MRF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = n_scen * robot_count;
+  dim3 block(64), grid((unsigned)((rows + 63) / 64));
+  if (h->cfg.scalar == MRF_F64) {
+    using T = double;
+    return launch(h, mrf::k_step_predict<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
+                  (int)robot_count, (T*)q_io, (const T*)qdot, (T*)sph_own);
+  }
+  using T = float;
+  return launch(h, mrf::k_step_predict<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
+                (int)robot_count, (T*)q_io, (const T*)qdot, (T*)sph_own);
+}
+
+int mrf_step_action(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
+                    void* qdot_io, const void* params, const void* sph_all, void* sumsq_io, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7 || h->cfg.mode != MRF_MODE_VEL)
+    return fail(h, MRF_E_CONFIG, "sharded rollout needs the panda7 model in mode 'vel'");
+  if (n_scen < 0 || robot_first < 0 || robot_count < 1 || robot_first + robot_count > h->cfg.n_robots || !q ||
+      !qdot_io || !params || !sph_all || !sumsq_io)
+    return fail(h, MRF_E_ARG, "bad argument");
+  if (n_scen == 0) return MRF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = n_scen * robot_count;
+  dim3 block(256), grid((unsigned)((rows + 255) / 256));
+  if (h->cfg.scalar == MRF_F64) {
+    using T = double;
+    return launch(h, mrf::k_step_action<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
+                  (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all, (T*)sumsq_io);
+  }
+  using T = float;
+  return launch(h, mrf::k_step_action<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
+                (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all, (T*)sumsq_io);
+}
+
+}  // extern "C"

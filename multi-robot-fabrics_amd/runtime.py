@@ -1,0 +1,155 @@
+"""Thin torch-tensor front of the C ABI (include/mrf.h): one `FabricHandle` per (config, device).
+
+torch is plumbing here -- device memory, streams -- and nothing else: every numeric result comes from
+the HIP kernels behind csrc/libmrf_hip.so.  There is no CPU path; constructing a handle without the
+library or without a GPU raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+
+
+class MrfError(RuntimeError):
+    pass
+
+
+def _dtype(cfg):
+    return torch.float64 if cfg.scalar == abi.F64 else torch.float32
+
+
+class FabricHandle:
+    """Owns an `mrf_handle` (immutable constants on the device).  Not thread-safe, like the C handle."""
+
+    def __init__(self, cfg, device=0):
+        self.lib = abi.load_library()
+        if not torch.cuda.is_available():
+            raise MrfError("no HIP device visible to torch; the fabric solve has no CPU fallback")
+        self.cfg = cfg.copy()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self.dtype = _dtype(cfg)
+        self.dof = 7 if cfg.model == abi.MODEL_PANDA7 else 3
+        self._h = C.c_void_p()
+        rc = self.lib.mrf_create(C.byref(self.cfg), self.device.index, C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.mrf_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self.lib.mrf_destroy(self._h)
+                self._h = C.c_void_p()
+            raise MrfError(f"mrf_create failed: {abi.STATUS_TEXT.get(rc, rc)} {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mrf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc):
+        if rc != 0:
+            raise MrfError(f"{abi.STATUS_TEXT.get(rc, rc)}: {self.lib.mrf_last_error(self._h).decode()}")
+
+    def tensor(self, a):
+        """Host/any array -> contiguous device tensor of the handle's scalar type."""
+        return torch.as_tensor(a, dtype=self.dtype).to(self.device).contiguous()
+
+    def _arg(self, t, shape=None, name="tensor"):
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor) or t.dtype != self.dtype or t.device != self.device or not t.is_contiguous():
+            raise MrfError(f"{name}: expected a contiguous {self.dtype} tensor on {self.device}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise MrfError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _stream(stream):
+        s = torch.cuda.current_stream() if stream is None else stream
+        return C.c_void_p(s.cuda_stream)
+
+    # ------------------------------------------------------------------ entry points
+    def compute_action(self, q, qdot, params, obst_x=None, obst_v=None, obst_a=None, obst_r=None,
+                       want_qddot=False, stream=None):
+        """q,qdot [dof,rows]; params [29,rows]; obst_x/v/a [M,3,rows]; obst_r [M,rows] -> action [dof,rows]."""
+        rows = q.shape[1]
+        M = 0 if obst_x is None else obst_x.shape[0]
+        act = torch.empty((self.dof, rows), dtype=self.dtype, device=self.device)
+        qdd = torch.empty_like(act) if want_qddot else None
+        rc = self.lib.mrf_compute_action(
+            self._h, rows, self._arg(q, (self.dof, rows), "q"), self._arg(qdot, (self.dof, rows), "qdot"),
+            self._arg(params, (abi.NPARAM, rows), "params"), M, self._arg(obst_x, (M, 3, rows), "obst_x"),
+            self._arg(obst_v, (M, 3, rows), "obst_v"), self._arg(obst_a, (M, 3, rows), "obst_a"),
+            self._arg(obst_r, (M, rows), "obst_r"), self._arg(qdd), self._arg(act), self._stream(stream))
+        self._check(rc)
+        return (act, qdd) if want_qddot else act
+
+    def rollout(self, q0, qdot0, params, want_traj=False, stream=None):
+        """Coupled joint-space rollout; rows = n_scenarios * n_robots -> avg_vel [rows] (, traj_q, traj_qdot)."""
+        rows = q0.shape[1]
+        N, H = self.cfg.n_robots, self.cfg.horizon
+        if rows % N:
+            raise MrfError("rows must be a multiple of n_robots")
+        avg = torch.empty((rows,), dtype=self.dtype, device=self.device)
+        tq = torch.empty((H, self.dof, rows), dtype=self.dtype, device=self.device) if want_traj else None
+        tqd = torch.empty_like(tq) if want_traj else None
+        rc = self.lib.mrf_rollout(self._h, rows // N, self._arg(q0, (self.dof, rows), "q0"),
+                                  self._arg(qdot0, (self.dof, rows), "qdot0"),
+                                  self._arg(params, (abi.NPARAM, rows), "params"), self._arg(avg), self._arg(tq),
+                                  self._arg(tqd), self._stream(stream))
+        self._check(rc)
+        return (avg, tq, tqd) if want_traj else avg
+
+    def rollout_cartesian(self, q0, qdot0, params, obst_x0, obst_v, obst_a, obst_r, want_traj=False, stream=None):
+        rows = q0.shape[1]
+        H = self.cfg.horizon
+        M = 0 if obst_x0 is None else obst_x0.shape[0]
+        avg = torch.empty((rows,), dtype=self.dtype, device=self.device)
+        tq = torch.empty((H, self.dof, rows), dtype=self.dtype, device=self.device) if want_traj else None
+        tqd = torch.empty_like(tq) if want_traj else None
+        rc = self.lib.mrf_rollout_cartesian(
+            self._h, rows, self._arg(q0, (self.dof, rows), "q0"), self._arg(qdot0, (self.dof, rows), "qdot0"),
+            self._arg(params, (abi.NPARAM, rows), "params"), M, self._arg(obst_x0, (M, 3, rows), "obst_x0"),
+            self._arg(obst_v, (M, 3, rows), "obst_v"), self._arg(obst_a, (M, 3, rows), "obst_a"),
+            self._arg(obst_r, (M, rows), "obst_r"), self._arg(avg), self._arg(tq), self._arg(tqd),
+            self._stream(stream))
+        self._check(rc)
+        return (avg, tq, tqd) if want_traj else avg
+
+    def fk_spheres(self, q, qdot=None, stream=None):
+        """-> x, v, a  each [S,3,rows]  (v, a None when qdot is None)."""
+        rows = q.shape[1]
+        S = self.cfg.n_spheres
+        x = torch.empty((S, 3, rows), dtype=self.dtype, device=self.device)
+        v = torch.empty_like(x) if qdot is not None else None
+        a = torch.empty_like(x) if qdot is not None else None
+        rc = self.lib.mrf_fk_spheres(self._h, rows, self._arg(q, (self.dof, rows), "q"),
+                                     self._arg(qdot, (self.dof, rows), "qdot"), self._arg(x), self._arg(v),
+                                     self._arg(a), self._stream(stream))
+        self._check(rc)
+        return x, v, a
+
+    def step_predict(self, n_scen, robot_first, robot_count, q_io, qdot, sph_own, stream=None):
+        rows = n_scen * robot_count
+        S = self.cfg.n_spheres
+        rc = self.lib.mrf_step_predict(self._h, n_scen, robot_first, robot_count,
+                                       self._arg(q_io, (self.dof, rows), "q_io"),
+                                       self._arg(qdot, (self.dof, rows), "qdot"),
+                                       self._arg(sph_own, (robot_count, S, 9, n_scen), "sph_own"),
+                                       self._stream(stream))
+        self._check(rc)
+
+    def step_action(self, n_scen, robot_first, robot_count, q, qdot_io, params, sph_all, sumsq_io, stream=None):
+        rows = n_scen * robot_count
+        S, N = self.cfg.n_spheres, self.cfg.n_robots
+        rc = self.lib.mrf_step_action(self._h, n_scen, robot_first, robot_count, self._arg(q, (self.dof, rows), "q"),
+                                      self._arg(qdot_io, (self.dof, rows), "qdot_io"),
+                                      self._arg(params, (abi.NPARAM, rows), "params"),
+                                      self._arg(sph_all, (N, S, 9, n_scen), "sph_all"),
+                                      self._arg(sumsq_io, (rows,), "sumsq_io"), self._stream(stream))
+        self._check(rc)

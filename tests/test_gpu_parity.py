@@ -1,0 +1,280 @@
+"""GPU parity: HIP kernels through the C ABI vs the float64 CPU oracle on the same seeded inputs.
+
+Tolerances: f64 kernels <= 1e-9 relative on qddot / actions / trajectories;
+f32 kernels <= 1e-4 relative + 1e-5 absolute on the well-conditioned set (all barrier coordinates >= 0.05).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.runtime import FabricHandle
+
+pytestmark = pytest.mark.gpu
+
+F64_RTOL = 1e-9
+F32_RTOL, F32_ATOL = 1e-4, 1e-5
+
+
+def relerr(got, want):
+    return float(np.abs(got - want).max() / max(1e-300, np.abs(want).max()))
+
+
+def _with_scalar(cfg, scalar):
+    c = cfg.copy()
+    c.scalar = scalar
+    return c
+
+
+def _obstacles_from_other_robots(cfg, batch, oracle, extra=0, seed=0):
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
+    if extra:
+        rng = np.random.default_rng(seed)
+        rows = ox.shape[2]
+        ex = np.stack([rng.uniform(-0.5, 1.5, (extra, rows)), rng.uniform(-1.0, 1.0, (extra, rows)),
+                       rng.uniform(2.2, 2.8, (extra, rows))], axis=1)       # far above the arms
+        ox = np.concatenate([ox, ex]); ov = np.concatenate([ov, rng.uniform(-0.2, 0.2, ex.shape)])
+        oa = np.concatenate([oa, rng.uniform(-0.2, 0.2, ex.shape)]); orad = np.concatenate([orad, np.full((extra, rows), 0.1)])
+    return ox, ov, oa, orad
+
+
+@pytest.mark.parametrize("scalar", [abi.F64, abi.F32])
+@pytest.mark.parametrize("n_robots,n_scen", [(2, 129), (3, 43)])
+def test_compute_action_panda(oracle, scalar, n_robots, n_scen):
+    cfg = _with_scalar(config.panda_config(n_robots=n_robots, horizon=1), scalar)
+    batch = scenarios.panda_batch(cfg, n_scen, seed=11)
+    ox, ov, oa, orad = _obstacles_from_other_robots(cfg, batch, oracle, extra=2)
+    want_qdd, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    h = FabricHandle(cfg, 0)
+    act, qdd = h.compute_action(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), h.tensor(ox),
+                                h.tensor(ov), h.tensor(oa), h.tensor(orad), want_qddot=True)
+    torch.cuda.synchronize()
+    act, qdd = act.cpu().numpy().astype(np.float64), qdd.cpu().numpy().astype(np.float64)
+    if scalar == abi.F64:
+        assert relerr(qdd, want_qdd) < F64_RTOL
+        assert relerr(act, want_act) < F64_RTOL
+    else:
+        assert np.allclose(qdd, want_qdd, rtol=F32_RTOL, atol=F32_ATOL * max(1.0, np.abs(want_qdd).max()))
+        assert np.allclose(act, want_act, rtol=F32_RTOL, atol=F32_ATOL)
+
+
+def test_compute_action_static_and_grasp(oracle):
+    cfg = config.panda_config(n_robots=2, horizon=1)
+    batch = scenarios.panda_batch(cfg, 64, seed=5)
+    ox, ov, oa, orad = _obstacles_from_other_robots(cfg, batch, oracle)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"])
+    # static obstacles: v, a omitted (NULL) == explicit zeros == oracle with zeros
+    a0 = h.compute_action(q, qd, prm, h.tensor(ox), None, None, h.tensor(orad))
+    a1 = h.compute_action(q, qd, prm, h.tensor(ox), h.tensor(np.zeros_like(ov)), h.tensor(np.zeros_like(oa)), h.tensor(orad))
+    _, want = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, None, None, orad)
+    assert torch.equal(a0, a1)
+    assert relerr(a0.cpu().numpy(), want) < F64_RTOL
+    # grasp planner: no collision links -> no obstacle and no plane leaves (EXJ:160-166)
+    cg = config.panda_config(n_robots=2, horizon=1, n_ego=0)
+    hg = FabricHandle(cg, 0)
+    ag = hg.compute_action(q, qd, prm, h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad))
+    _, want_g = oracle.compute_action(cg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    _, want_g0 = oracle.compute_action(cg, batch["q"], batch["qdot"], batch["params"])
+    assert relerr(ag.cpu().numpy(), want_g) < F64_RTOL
+    assert np.array_equal(want_g, want_g0)
+    # no obstacles at all
+    an = h.compute_action(q, qd, prm)
+    _, want_n = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"])
+    assert relerr(an.cpu().numpy(), want_n) < F64_RTOL
+
+
+def test_compute_action_edge_cases(oracle):
+    """robot at rest (all xdot = 0 -> gates at 0.5), q[6] exactly at its goal (|x| = 0 attractor), empty batch."""
+    cfg = config.panda_config(n_robots=2, horizon=1)
+    batch = scenarios.panda_batch(cfg, 8, seed=2)
+    batch["qdot"][:] = 0.0
+    batch["q"][6, :] = math.pi / 4
+    ox, ov, oa, orad = _obstacles_from_other_robots(cfg, batch, oracle)
+    h = FabricHandle(cfg, 0)
+    act = h.compute_action(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), h.tensor(ox),
+                           h.tensor(ov), h.tensor(oa), h.tensor(orad))
+    _, want = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    assert np.isfinite(want).all()
+    assert relerr(act.cpu().numpy(), want) < F64_RTOL
+    empty = h.compute_action(h.tensor(np.zeros((7, 0))), h.tensor(np.zeros((7, 0))), h.tensor(np.zeros((abi.NPARAM, 0))))
+    assert empty.shape == (7, 0)
+
+
+@pytest.mark.parametrize("obst_dim", [3, 2])
+def test_compute_action_planar(oracle, obst_dim):
+    """4 point robots, 6 scene obstacles + 3 other robots (example_pointmasses_static.py:142-199)."""
+    cfg = config.planar3_config(n_robots=4, obst_dim=obst_dim)
+    rng = np.random.default_rng(4)
+    rows = 4 * 33
+    q = np.stack([rng.uniform(-2.5, 2.5, rows), rng.uniform(-2.5, 3.7, rows), rng.uniform(-1, 1, rows)])
+    qd = rng.uniform(-0.5, 0.5, (3, rows))
+    prm = np.zeros((abi.NPARAM, rows))
+    prm[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 2] = rng.uniform(-2.5, 2.5, (2, rows))
+    prm[abi.P_WEIGHT_GOAL_0] = 1.0
+    prm[abi.P_RADIUS_BODY] = 0.2
+    M = 9
+    ang = rng.uniform(0, 2 * math.pi, (M, rows))
+    dist = rng.uniform(1.5, 4.0, (M, rows))
+    ox = np.stack([q[0] + dist * np.cos(ang), q[1] + dist * np.sin(ang), np.zeros((M, rows))], axis=1)
+    ov = rng.uniform(-0.3, 0.3, (M, 3, rows)); oa = rng.uniform(-0.3, 0.3, (M, 3, rows))
+    orad = np.concatenate([np.ones((6, rows)), np.full((3, rows), 0.2)])
+    want_qdd, want_act = oracle.compute_action(cfg, q, qd, prm, ox, ov, oa, orad)
+    h = FabricHandle(cfg, 0)
+    act = h.compute_action(h.tensor(q), h.tensor(qd), h.tensor(prm), h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad))
+    assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
+
+
+@pytest.mark.parametrize("scalar", [abi.F64, abi.F32])
+@pytest.mark.parametrize("n_robots,horizon,n_scen,mask,dynamic", [
+    (2, 20, 37, 0, 1),        # BASELINE config 3: 2-Panda RF H=20
+    (3, 30, 25, 0b110, 1),    # BASELINE config 4: 3-Panda RF-CV H=30
+    (3, 6, 22, 0, 0),         # static fabrics: exchanged v, a zeroed (FPJ:215-217); 22 scenarios -> ragged last wave
+    (1, 5, 70, 0, 1),         # a single robot: no obstacles at all
+])
+def test_rollout_jointspace(oracle, scalar, n_robots, horizon, n_scen, mask, dynamic):
+    cfg = _with_scalar(config.panda_config(n_robots=n_robots, horizon=horizon, dynamic=dynamic), scalar)
+    cfg.goal_estimate_mask = mask
+    batch = scenarios.panda_batch(cfg, n_scen, seed=21, x_min=0.08)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    avg, tq, tqd = h.rollout(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), want_traj=True)
+    avg_only = h.rollout(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]))
+    torch.cuda.synchronize()
+    assert torch.equal(avg, avg_only)
+    avg, tq, tqd = (t.cpu().numpy().astype(np.float64) for t in (avg, tq, tqd))
+    if scalar == abi.F64:
+        assert relerr(tq, want_q) < F64_RTOL
+        assert relerr(tqd, want_qd) < F64_RTOL
+        assert relerr(avg, want_avg) < F64_RTOL
+    else:
+        assert np.allclose(tqd, want_qd, rtol=1e-3, atol=1e-4)
+        assert np.allclose(tq, want_q, rtol=1e-4, atol=1e-5)
+        assert np.allclose(avg, want_avg, rtol=1e-3, atol=1e-5)
+
+
+def test_rollout_eight_pandas(oracle):
+    """BASELINE config 5 shape: 8 Pandas on the build-defined ring, 20 spheres per robot with link-local offsets."""
+    cfg = config.panda_config(n_robots=8, horizon=4)
+    links, offs = config.sphere_offsets_per_link(3)
+    keep = [i for i in range(len(links))][:20]
+    config.set_spheres(cfg, [links[i] for i in keep], [offs[i] for i in keep])
+    cfg.goal_estimate_mask = 0xFE
+    batch = scenarios.panda_batch(cfg, 9, seed=8, x_min=0.3, q_spread=0.15)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    avg, tq, tqd = h.rollout(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+
+
+@pytest.mark.parametrize("scalar", [abi.F64, abi.F32])
+def test_rollout_cartesian(oracle, scalar):
+    cfg = _with_scalar(config.panda_config(n_robots=2, horizon=10), scalar)
+    batch = scenarios.panda_batch(cfg, 150, seed=31, x_min=0.1)
+    ox, ov, oa, orad = _obstacles_from_other_robots(cfg, batch, oracle)
+    oa[:] = 0.0   # forward_planner_Cartesian.py:33 a_obsts_dyn = 0
+    want_avg, want_q, want_qd = oracle.rollout_cartesian(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad, traj=True)
+    h = FabricHandle(cfg, 0)
+    avg, tq, tqd = h.rollout_cartesian(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]),
+                                       h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad), want_traj=True)
+    avg, tq, tqd = (t.cpu().numpy().astype(np.float64) for t in (avg, tq, tqd))
+    if scalar == abi.F64:
+        assert relerr(tqd, want_qd) < F64_RTOL
+        assert relerr(tq, want_q) < F64_RTOL
+        assert relerr(avg, want_avg) < F64_RTOL
+    else:
+        assert np.allclose(tqd, want_qd, rtol=1e-3, atol=1e-4)
+        assert np.allclose(avg, want_avg, rtol=1e-3, atol=1e-5)
+
+
+def test_fk_spheres_with_offsets(oracle):
+    cfg = config.panda_config(n_robots=3, horizon=1)
+    links, offs = config.sphere_offsets_per_link(4)
+    config.set_spheres(cfg, links, offs)
+    batch = scenarios.panda_batch(cfg, 40, seed=41)
+    wx, wv, wa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    h = FabricHandle(cfg, 0)
+    x, v, a = h.fk_spheres(h.tensor(batch["q"]), h.tensor(batch["qdot"]))
+    assert relerr(x.cpu().numpy(), wx) < 1e-12
+    assert relerr(v.cpu().numpy(), wv) < 1e-11
+    assert relerr(a.cpu().numpy(), wa) < 1e-11
+    x_only, v_none, _ = h.fk_spheres(h.tensor(batch["q"]))
+    assert v_none is None and torch.equal(x_only, x)
+
+
+@pytest.mark.parametrize("robot_first,robot_count", [(0, 3), (1, 1), (1, 2)])
+def test_sharded_step_matches_fused_rollout(oracle, robot_first, robot_count):
+    """predict -> (gather) -> action for a subset of robots reproduces the fused rollout's trajectory."""
+    N, H, B = 3, 7, 19
+    cfg = config.panda_config(n_robots=N, horizon=H)
+    batch = scenarios.panda_batch(cfg, B, seed=51, x_min=0.08)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    S = cfg.n_spheres
+    sel = np.array([s * N + robot_first + l for s in range(B) for l in range(robot_count)])
+    q = h.tensor(batch["q"][:, sel]); qd = h.tensor(batch["qdot"][:, sel]); prm = h.tensor(batch["params"][:, sel])
+    sumsq = torch.zeros(B * robot_count, dtype=torch.float64, device="cuda")
+    for k in range(H):
+        sph_own = torch.empty((robot_count, S, 9, B), dtype=torch.float64, device="cuda")
+        h.step_predict(B, robot_first, robot_count, q, qd, sph_own)
+        # spheres of the robots this "rank" does not own come from the oracle trajectory (stand-in for the all-gather)
+        qk, qdk = want_q[k], (want_qd[k - 1] if k else batch["qdot"])
+        sx, sv, sa = oracle.fk_spheres(cfg, qk, qdk)
+        sph_all = np.concatenate([sx, sv, sa], axis=1).reshape(S, 9, B, N).transpose(3, 0, 1, 2).copy()
+        sph_all_t = h.tensor(sph_all)
+        assert relerr(sph_own.cpu().numpy(), sph_all[robot_first:robot_first + robot_count]) < 1e-9
+        sph_all_t[robot_first:robot_first + robot_count] = sph_own
+        h.step_action(B, robot_first, robot_count, q, qd, prm, sph_all_t, sumsq)
+        assert relerr(q.cpu().numpy(), want_q[k][:, sel]) < F64_RTOL
+        assert relerr(qd.cpu().numpy(), want_qd[k][:, sel]) < F64_RTOL
+    assert relerr((sumsq / (H * 7)).cpu().numpy(), want_avg[sel]) < F64_RTOL
+
+
+# ---------------------------------------------------------------------------------- properties at full size
+def test_properties_at_bench_size():
+    """Size-independent properties on the full bench batch (no oracle: too slow at this size):
+    obstacle-permutation invariance, static == dynamic with zero v/a, H=1 rollout == Euler step + compute_action."""
+    N, B = 3, 4096
+    cfg = config.panda_config(n_robots=N, horizon=1)
+    batch = scenarios.panda_batch(cfg, B, seed=61)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"])
+    # H=1 rollout: q1 = q + dt*qd, obstacles = other robots' link origins at (q1, qd)
+    avg, tq, tqd = h.rollout(q, qd, prm, want_traj=True)
+    q1 = q + cfg.dt * qd
+    assert torch.allclose(tq[0], q1, rtol=0, atol=1e-15)
+    sx, sv, sa = h.fk_spheres(q1, qd)
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
+    act = h.compute_action(q1, qd, prm, ox, ov, oa, orad)
+    assert float((act - tqd[0]).abs().max() / tqd[0].abs().max()) < 1e-10
+    assert torch.allclose(avg, (act ** 2).sum(0) / 7, rtol=1e-10, atol=0)
+    # permutation of the obstacle list leaves the action unchanged up to summation order
+    perm = torch.randperm(ox.shape[0], device="cuda")
+    act_p = h.compute_action(q1, qd, prm, ox[perm].contiguous(), ov[perm].contiguous(), oa[perm].contiguous(),
+                             orad[perm].contiguous())
+    assert float((act - act_p).abs().max() / act.abs().max()) < 1e-10
+    # the static planner (dynamic=0 rollout) equals compute_action with v = a = 0
+    cs = config.panda_config(n_robots=N, horizon=1, dynamic=0)
+    hs = FabricHandle(cs, 0)
+    _, _, tqd_s = hs.rollout(q, qd, prm, want_traj=True)
+    act_s = h.compute_action(q1, qd, prm, ox, None, None, orad)
+    assert float((act_s - tqd_s[0]).abs().max() / tqd_s[0].abs().max()) < 1e-10
+    assert np.isfinite(act.cpu().numpy()).all()
+
+
+def test_create_rejects_bad_config():
+    from multi_robot_fabrics_amd.runtime import MrfError
+    cfg = config.panda_config(n_robots=2, horizon=1)
+    cfg.n_ego = 4
+    with pytest.raises(MrfError):
+        FabricHandle(cfg, 0)
+    cfg = config.panda_config(n_robots=2, horizon=1)
+    cfg.mode = abi.MODE_ACC
+    h = FabricHandle(cfg, 0)
+    z = h.tensor(np.zeros((7, 2)))
+    with pytest.raises(MrfError):
+        h.rollout(z, z, h.tensor(np.zeros((abi.NPARAM, 2))))
