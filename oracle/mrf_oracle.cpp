@@ -22,6 +22,8 @@
 //   goal estimate x_ee + 20*0.01*v_ee         examples/example_pandas_cartesian.py:355-357
 //   chain constants                           examples/simulation_environments/urdfs/panda_with_finger.urdf:98-107,150-158,
 //                                             201-209,253-261,326-334,378-386,451-459,461-465; pointRobot1.urdf:91-113
+#include <omp.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -484,13 +486,21 @@ void robot_spheres(const mrf_config& cfg, int robot, const double* q, const doub
 
 extern "C" {
 
+// threads used by the batch loops below (one scenario / row per thread); returns the previous maximum
+int mrfo_set_threads(int n) {
+  int prev = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return prev;
+}
+
 // Same array layouts as include/mrf.h, host pointers, double only.
 int mrfo_compute_action(const mrf_config* cfg, int64_t rows, const double* q, const double* qdot, const double* params,
                         int32_t n_obst, const double* ox, const double* ov, const double* oa, const double* orad,
                         double* qddot_out, double* action_out) {
   const int n = dof_of(*cfg);
-  std::vector<Obst> obst(n_obst);
+#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < rows; ++r) {
+    std::vector<Obst> obst(n_obst);
     double qv[DOF_MAX], qdv[DOF_MAX], prm[MRF_NPARAM], qdd[DOF_MAX], act[DOF_MAX];
     for (int j = 0; j < n; ++j) {
       qv[j] = q[j * rows + r];
@@ -546,6 +556,7 @@ int mrfo_specs(const mrf_config* cfg, int32_t robot, const double* q, const doub
 int mrfo_fk_spheres(const mrf_config* cfg, int64_t rows, const double* q, const double* qdot, double* x_out,
                     double* v_out, double* a_out) {
   const int n = dof_of(*cfg);
+#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < rows; ++r) {
     double qv[DOF_MAX], qdv[DOF_MAX];
     for (int j = 0; j < n; ++j) {
@@ -572,8 +583,9 @@ int mrfo_rollout(const mrf_config* cfg, int64_t n_scen, const double* q0, const 
   const int n = dof_of(*cfg), N = cfg->n_robots, S = cfg->n_spheres, H = cfg->horizon;
   const int64_t rows = n_scen * N;
   if (cfg->mode != MRF_MODE_VEL) return -2;
-  std::vector<Obst> obst((size_t)S * (N - 1));
+#pragma omp parallel for schedule(static)
   for (int64_t sc = 0; sc < n_scen; ++sc) {
+    std::vector<Obst> obst((size_t)S * (N - 1));
     double q[MRF_MAX_ROBOTS][DOF_MAX], qd[MRF_MAX_ROBOTS][DOF_MAX];
     double prm[MRF_MAX_ROBOTS][MRF_NPARAM], sumsq[MRF_MAX_ROBOTS];
     for (int i = 0; i < N; ++i) {
@@ -639,8 +651,9 @@ int mrfo_rollout_cartesian(const mrf_config* cfg, int64_t rows, const double* q0
                            const double* params, int32_t n_obst, const double* ox0, const double* ov, const double* oa,
                            const double* orad, double* avg_out, double* traj_q, double* traj_qd) {
   const int n = dof_of(*cfg), H = cfg->horizon;
-  std::vector<Obst> obst(n_obst);
+#pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < rows; ++r) {
+    std::vector<Obst> obst(n_obst);
     double q[DOF_MAX], qd[DOF_MAX], prm[MRF_NPARAM], qdd[DOF_MAX], act[DOF_MAX];
     for (int j = 0; j < n; ++j) {
       q[j] = q0[j * rows + r];

@@ -106,3 +106,8 @@ def rollout_cartesian(cfg, q0, qdot0, params, ox0, ov, oa, orad, traj=False):
                                       _p(ox0), _p(ov), _p(oa), _p(orad), _p(avg), _p(tq), _p(tqd))
     assert rc == 0
     return avg, tq, tqd
+
+
+def set_threads(n):
+    """Threads for the oracle's batch loops (OpenMP, one scenario/row per thread); returns the previous max."""
+    return lib().mrfo_set_threads(C.c_int(int(n)))
