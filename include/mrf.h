@@ -126,11 +126,14 @@ int64_t mrf_config_sizeof(void); /* sizeof(mrf_config) as compiled, for FFI layo
 /* Replaces ParameterizedFabricPlanner.compute_action (EXJ:441,444; EXC:447,449; FPC:150-190).
  *   q, qdot      [dof][rows]
  *   params       [MRF_NPARAM][rows]
- *   obst_x/v/a   [n_obst][3][rows]   obst_r [n_obst][rows]   (static obstacles: v = a = 0)
+ *   obst_x/v/a   [n_obst][3][rows]   obst_r [n_obst][rows]
+ *                the first n_obst_static obstacles are the planner's static spheres (x_obsts / radius_obsts:
+ *                full 3-D distance, v and a not read); the rest are its dynamic spheres (x_obsts_dynamic, ...,
+ *                distance in cfg.obst_dim dimensions).  obst_v / obst_a may be NULL (= zeros).
  *   qddot_out    [dof][rows] (may be NULL)     action_out [dof][rows]
  */
 int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
-                       int32_t n_obst, const void* obst_x, const void* obst_v, const void* obst_a,
+                       int32_t n_obst, int32_t n_obst_static, const void* obst_x, const void* obst_v, const void* obst_a,
                        const void* obst_r, void* qddot_out, void* action_out, void* stream);
 
 /* Replaces ForwardFabricsPlanner.get_velocity_rollouts / rollouts_numerical (FPJ:190-249,298-423):
@@ -145,7 +148,7 @@ int mrf_rollout(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* 
 /* Replaces FabricsRollouts.get_velocity_rollouts / rollouts_numerical (FPC:347-489,538-563):
  * per-row independent rollout, action-then-step, obstacles at constant Cartesian velocity. */
 int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,
-                          int32_t n_obst, const void* obst_x0, const void* obst_v, const void* obst_a,
+                          int32_t n_obst, int32_t n_obst_static, const void* obst_x0, const void* obst_v, const void* obst_a,
                           const void* obst_r, void* avg_vel_out, void* traj_q, void* traj_qdot, void* stream);
 
 /* Replaces the fk/jac/jac_dot helper evaluations (utils.py:16-54,87-119; FPJ:82-100; UFK:3-33):

@@ -112,11 +112,11 @@ def load_library(path=None):
     lib.mrf_abi_version.restype = C.c_int
     lib.mrf_config_sizeof.argtypes = []
     lib.mrf_config_sizeof.restype = C.c_int64
-    lib.mrf_compute_action.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_compute_action.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mrf_compute_action.restype = C.c_int
     lib.mrf_rollout.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.mrf_rollout.restype = C.c_int
-    lib.mrf_rollout_cartesian.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_rollout_cartesian.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mrf_rollout_cartesian.restype = C.c_int
     lib.mrf_fk_spheres.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.mrf_fk_spheres.restype = C.c_int

@@ -304,8 +304,7 @@ struct EgoPts {
 // a_o is the obstacle's reference acceleration as the reference passes it (already sign-carrying).
 template <typename T, int NP>
 __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* xo,
-                                                    const T* vo, const T* a_o, T ro, EgoAcc<T, NP>& acc) {
-  const bool planar = cfg.obst_dim == 2;
+                                                    const T* vo, const T* a_o, T ro, bool planar, EgoAcc<T, NP>& acc) {
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
     T dx[3] = {E.p[g][0] - xo[0], E.p[g][1] - xo[1], planar ? T(0) : E.p[g][2] - xo[2]};

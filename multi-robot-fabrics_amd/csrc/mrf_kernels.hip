@@ -43,7 +43,7 @@ __device__ __forceinline__ void panda_trig(PandaRow<T>& R) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                        const T* __restrict__ q, const T* __restrict__ qd,
-                                                       const T* __restrict__ prm, int n_obst,
+                                                       const T* __restrict__ prm, int n_obst, int n_static,
                                                        const T* __restrict__ ox, const T* __restrict__ ov,
                                                        const T* __restrict__ oa, const T* __restrict__ orad,
                                                        T* __restrict__ qdd_out, T* __restrict__ act_out) {
@@ -62,15 +62,16 @@ __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restric
   if (cfg.n_ego > 0) {
 #pragma unroll 1
     for (int m = 0; m < n_obst; ++m) {
+      const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
       T xo[3], vo[3], ao[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
         xo[c] = ox[idx];
-        vo[c] = ov ? ov[idx] : T(0);
-        ao[c] = oa ? oa[idx] : T(0);
+        vo[c] = (ov && !is_static) ? ov[idx] : T(0);
+        ao[c] = (oa && !is_static) ? oa[idx] : T(0);
       }
-      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], acc);
+      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], !is_static && cfg.obst_dim == 2, acc);
     }
   }
   T qdd[7], act[7];
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                         const T* __restrict__ q, const T* __restrict__ qd,
-                                                        const T* __restrict__ prm, int n_obst,
+                                                        const T* __restrict__ prm, int n_obst, int n_static,
                                                         const T* __restrict__ ox, const T* __restrict__ ov,
                                                         const T* __restrict__ oa, const T* __restrict__ orad,
                                                         T* __restrict__ qdd_out, T* __restrict__ act_out) {
@@ -107,15 +108,16 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
   if (cfg.n_ego > 0) {
 #pragma unroll 1
     for (int m = 0; m < n_obst; ++m) {
+      const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
       T xo[3], vo[3], ao[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
         xo[c] = ox[idx];
-        vo[c] = ov ? ov[idx] : T(0);
-        ao[c] = oa ? oa[idx] : T(0);
+        vo[c] = (ov && !is_static) ? ov[idx] : T(0);
+        ao[c] = (oa && !is_static) ? oa[idx] : T(0);
       }
-      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], acc);
+      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], !is_static && cfg.obst_dim == 2, acc);
     }
   }
   T qdd[3], act[3];
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                 vv[c] = cfg.dynamic ? v[c] : T(0);               // FPJ:215-220
                 aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);   // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
               }
-              accumulate_obstacle(cfg, E, x, vv, aa, cfg.sphere_r[s], acc);
+              accumulate_obstacle(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
             });
       }
     }
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
-                                                             const T* __restrict__ prm, int n_obst,
+                                                             const T* __restrict__ prm, int n_obst, int n_static,
                                                              const T* __restrict__ ox0, const T* __restrict__ ov,
                                                              const T* __restrict__ oa, const T* __restrict__ orad,
                                                              T* __restrict__ avg_out, T* __restrict__ traj_q,
@@ -260,15 +262,16 @@ __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __r
     if (cfg.n_ego > 0) {
 #pragma unroll 1
       for (int m = 0; m < n_obst; ++m) {
+        const bool is_static = m < n_static;
         T xo[3], vo[3], ao[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
-          vo[c] = ov[idx];
+          vo[c] = is_static ? T(0) : ov[idx];
           xo[c] = ox0[idx] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
-          ao[c] = oa ? oa[idx] : T(0);
+          ao[c] = (oa && !is_static) ? oa[idx] : T(0);
         }
-        accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], acc);
+        accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], false, acc);
       }
     }
     T qdd[7], act[7];
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
           v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
           a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
         }
-        accumulate_obstacle(cfg, E, x, v, a, cfg.sphere_r[s], acc);
+        accumulate_obstacle(cfg, E, x, v, a, cfg.sphere_r[s], false, acc);
       }
     }
   }
@@ -676,11 +679,12 @@ const char* mrf_last_error(const mrf_handle* h) { return h ? h->err.c_str() : "n
   if (!(h)->dcfg) return fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)");
 
 int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
-                       int32_t n_obst, const void* ox, const void* ov, const void* oa, const void* orad,
+                       int32_t n_obst, int32_t n_obst_static, const void* ox, const void* ov, const void* oa, const void* orad,
                        void* qddot_out, void* action_out, void* stream) {
   MRF_CHECK_READY(h);
   if (rows == 0) return MRF_OK;  // empty batch: nothing to read or write, pointers may be NULL
-  if (rows < 0 || n_obst < 0 || !q || !qdot || !params || !action_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  if (rows < 0 || n_obst < 0 || n_obst_static < 0 || n_obst_static > n_obst || !q || !qdot || !params || !action_out)
+    return fail(h, MRF_E_ARG, "null/negative argument");
   if (n_obst > 0 && (!ox || !orad)) return fail(h, MRF_E_ARG, "obstacle arrays missing");
   if (rows == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -690,14 +694,14 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
     using T = double;
     auto k = panda ? mrf::k_action_panda<T> : mrf::k_action_planar<T>;
     return launch(h, k, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
-                  (const T*)params, (int)n_obst, (const T*)ox, (const T*)ov, (const T*)oa, (const T*)orad,
-                  (T*)qddot_out, (T*)action_out);
+                  (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
+                  (const T*)orad, (T*)qddot_out, (T*)action_out);
   }
   using T = float;
   auto k = panda ? mrf::k_action_panda<T> : mrf::k_action_planar<T>;
   return launch(h, k, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
-                (const T*)params, (int)n_obst, (const T*)ox, (const T*)ov, (const T*)oa, (const T*)orad,
-                (T*)qddot_out, (T*)action_out);
+                (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
+                (const T*)orad, (T*)qddot_out, (T*)action_out);
 }
 
 int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
@@ -723,26 +727,27 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
 }
 
 int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,
-                          int32_t n_obst, const void* ox0, const void* ov, const void* oa, const void* orad,
+                          int32_t n_obst, int32_t n_obst_static, const void* ox0, const void* ov, const void* oa, const void* orad,
                           void* avg_out, void* traj_q, void* traj_qd, void* stream) {
   MRF_CHECK_READY(h);
   if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "rollouts are defined for the panda7 model only");
   if (rows == 0) return MRF_OK;
-  if (rows < 0 || n_obst < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
-  if (n_obst > 0 && (!ox0 || !ov || !orad)) return fail(h, MRF_E_ARG, "obstacle arrays missing");
+  if (rows < 0 || n_obst < 0 || n_obst_static < 0 || n_obst_static > n_obst || !q0 || !qdot0 || !params || !avg_out)
+    return fail(h, MRF_E_ARG, "null/negative argument");
+  if (n_obst > 0 && (!ox0 || !orad || (n_obst > n_obst_static && !ov))) return fail(h, MRF_E_ARG, "obstacle arrays missing");
   if (rows == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
   if (h->cfg.scalar == MRF_F64) {
     using T = double;
     return launch(h, mrf::k_rollout_cart_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0,
-                  (const T*)qdot0, (const T*)params, (int)n_obst, (const T*)ox0, (const T*)ov, (const T*)oa,
-                  (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+                  (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0, (const T*)ov,
+                  (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
   }
   using T = float;
   return launch(h, mrf::k_rollout_cart_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0,
-                (const T*)qdot0, (const T*)params, (int)n_obst, (const T*)ox0, (const T*)ov, (const T*)oa,
-                (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+                (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0, (const T*)ov,
+                (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
 }
 
 int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot, void* x_out, void* v_out,

@@ -1,0 +1,68 @@
+"""Minimal mirror of mpscenes' GoalComposition as the reference uses it (example_pandas_Jointspace.py:25-62,
+361-365; example_pointmasses_static.py:61-83): a named dict of sub-goals with attribute access."""
+import numpy as np
+
+
+class _SubGoalConfig(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class SubGoal:
+    def __init__(self, name, content):
+        self._name = name
+        self._config = _SubGoalConfig(content)
+
+    def name(self):
+        return self._name
+
+    def weight(self):
+        return self._config["weight"]
+
+    def is_primary_goal(self):
+        return bool(self._config.get("is_primary_goal", False))
+
+    def indices(self):
+        return list(self._config["indices"])
+
+    def dimension(self):
+        return len(self._config["indices"])
+
+    def parent_link(self):
+        return self._config.get("parent_link")
+
+    def child_link(self):
+        return self._config.get("child_link")
+
+    def position(self):
+        return np.asarray(self._config["desired_position"], dtype=float)
+
+    def angle(self):
+        return self._config.get("angle")
+
+    def type(self):
+        return self._config["type"]
+
+
+class _CompositionConfig(dict):
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key) from None
+
+
+class GoalComposition:
+    def __init__(self, name, content_dict):
+        self._name = name
+        self._config = _CompositionConfig((k, _SubGoalConfig(v)) for k, v in content_dict.items())
+        self._sub_goals = [SubGoal(k, v) for k, v in content_dict.items()]
+
+    def sub_goals(self):
+        return self._sub_goals
+
+    def primary_goal(self):
+        for g in self._sub_goals:
+            if g.is_primary_goal():
+                return g
+        return self._sub_goals[0]

@@ -1,0 +1,98 @@
+"""Scenario constants and flags of the Panda examples, with the attribute names the reference's drivers read
+(examples/parameters_manipulators.py:4-181, examples/configs/panda_config.yaml:1-8).
+
+Only the planner-facing fields are kept; URDF/tray/table file locations belong to the simulator and are out of scope.
+N > 3 robots (the reference stops at 3, PM:72-73,119-120) use the build-defined ring of config.mount_positions.
+"""
+import copy
+
+import numpy as np
+
+from . import config as _config
+from . import scenarios as _scenarios
+
+
+class manipulator_parameters:
+    def __init__(self, nr_robots, n_obst_per_link=1):
+        N = nr_robots
+        self.dt = 0.01                       # PM:8
+        self.n_cubes = 6
+        self.nr_robots = N
+        self.dof = [7] * N
+        self.fabrics_mode = "vel"            # PM:12
+        self.nu = self.dof
+        self.nx = self.dof
+        self.nr_obsts = [0] * N
+        self.radius_obsts = [[] for _ in range(N)]
+        self.n_obst_per_link = n_obst_per_link
+        self.radius_sphere = 0.08            # PM:23
+        self.nr_constraints = [1] * N
+        self.collision_links_nrs = [list(range(1, 9)) for _ in range(N)]
+        self.collision_links = [["panda_link%d" % l for l in range(1, 9)] for _ in range(N)]
+        self.nr_obsts_dyn = [8 * (N - 1)] * N                      # one sphere per link in the rollouts (PM:28-33)
+        self.nr_obsts_dyn_all = [8 * (N - 1) * n_obst_per_link] * N
+        self.robot_types = ["panda"] * N
+        self.r_robots = [[self.radius_sphere] * 8 for _ in range(N)]
+        self.radius_body_panda_links = {str(l): np.array(self.radius_sphere) for l in range(3, 9)}   # PM:41-43
+        n_all = self.nr_obsts_dyn_all[0]
+        self.a_dyns_obsts = [[np.zeros(3)] * n_all for _ in range(N)]
+        self.r_dyns_obsts = [[self.radius_sphere] * n_all for _ in range(N)]
+
+        self.ROLLOUT_FABRICS = False
+        self.ROLLOUTS_PLOTTING = False
+        self.STATIC_OR_DYN_FABRICS = 0
+        self.RESOLVE_DEADLOCKS = True
+        self.ESTIMATE_GOAL = False
+        self.N_HORIZON = 2                   # PM:60
+        self.MPC_LAYER = False
+
+        self.z_table = _config.Z_TABLE
+        pos, yaw = _config.mount_positions(N)
+        self.mount_positions = pos
+        self.mount_yaws = yaw
+        self.mount_orientations = [np.array([0.0, 0.0, np.sin(y / 2), np.cos(y / 2)]) for y in yaw]
+        self.mount_transform = [_config.mount_transform(p, y) for p, y in zip(pos, yaw)]
+        self.mount_param = {"z_table": self.z_table, "mount_positions": pos, "mount_orientations": self.mount_orientations}
+        p0 = _scenarios.pos0(N)
+        self.pos0 = np.array([np.concatenate([p, [0.02, 0.02]]) for p in p0])
+        self.rotation_matrix_pandas = [_scenarios.ROT_GOAL_1.copy() for _ in range(N)]    # PM:121-122
+        self.start_goals = [list(g) for g in _scenarios.start_goals(N)]
+        self.constraints = [np.array([0.0, 0.0, 1.0, -self.z_table])] * N                  # PM:136
+
+    def get_mount_parameters(self):
+        return self.mount_param
+
+    def define_settings(self, ROLLOUT_FABRICS=False, ROLLOUTS_PLOTTING=False, STATIC_OR_DYN_FABRICS=0,
+                        RESOLVE_DEADLOCKS=True, ESTIMATE_GOAL=False, N_HORIZON=10, MPC_LAYER=False, n_obst_per_link=1):
+        self.ROLLOUT_FABRICS = ROLLOUT_FABRICS
+        self.ROLLOUTS_PLOTTING = ROLLOUTS_PLOTTING
+        self.STATIC_OR_DYN_FABRICS = STATIC_OR_DYN_FABRICS
+        self.RESOLVE_DEADLOCKS = RESOLVE_DEADLOCKS
+        self.ESTIMATE_GOAL = ESTIMATE_GOAL
+        self.N_HORIZON = N_HORIZON
+        self.MPC_LAYER = MPC_LAYER
+        self.n_obst_per_link = n_obst_per_link
+        return self.get_settings() + [n_obst_per_link]
+
+    def get_settings(self):
+        return [self.ROLLOUT_FABRICS, self.ROLLOUTS_PLOTTING, self.STATIC_OR_DYN_FABRICS, self.RESOLVE_DEADLOCKS,
+                self.ESTIMATE_GOAL, self.N_HORIZON, self.MPC_LAYER]
+
+    def set_horizon(self, n_horizon):
+        self.N_HORIZON = n_horizon
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+
+def load_yaml_settings(path):
+    """The eight keys of examples/configs/panda_config.yaml -> (manipulator_parameters, settings dict)."""
+    import yaml
+    with open(path, "r") as f:
+        setup = yaml.safe_load(f)
+    p = manipulator_parameters(nr_robots=setup["n_robots"], n_obst_per_link=setup["n_obst_per_link"])
+    p.define_settings(ROLLOUT_FABRICS=setup["ROLLOUT_FABRICS"], ROLLOUTS_PLOTTING=setup["ROLLOUTS_PLOTTING"],
+                      STATIC_OR_DYN_FABRICS=setup["STATIC_OR_DYN_FABRICS"], RESOLVE_DEADLOCKS=setup["RESOLVE_DEADLOCKS"],
+                      ESTIMATE_GOAL=setup["ESTIMATE_GOAL"], N_HORIZON=setup["N_HORIZON"],
+                      n_obst_per_link=setup["n_obst_per_link"])
+    return p, setup

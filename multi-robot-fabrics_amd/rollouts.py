@@ -1,0 +1,329 @@
+"""Rollout Fabrics with the reference's two class surfaces, evaluated by the HIP rollout kernels.
+
+    ForwardFabricsPlanner   multi_robot_fabrics/fabrics_planner/forward_planner_Jointspace.py:12-555
+                            (joint-space coupling: every robot's fabric sees the other robots' predicted spheres)
+    FabricsRollouts         multi_robot_fabrics/fabrics_planner/forward_planner_Cartesian.py:8-563
+                            (per-robot rollout, obstacles extrapolated at constant Cartesian velocity)
+
+The reference unrolls the horizon into one CasADi graph at construction time
+(`forward_multi_fabrics_symbolic`, `symbolic_forward_fabrics`); here those calls create the device handle, and
+the per-step entry points launch one persistent kernel.  The *_batch methods are the same entry points for
+many scenarios at once (device tensors in, device tensors out).
+"""
+import numpy as np
+
+from . import abi
+from . import config as _config
+from .kinematics import DM
+
+
+def _scalar(v):
+    return float(np.asarray(v, dtype=float).reshape(-1)[0])
+
+
+def _params_row(angle, constraint, weights, goals, radius_bodies):
+    p = np.zeros(abi.NPARAM)
+    g0 = np.asarray(goals[0], dtype=float).reshape(-1)
+    p[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3] = g0[:3]
+    p[abi.P_WEIGHT_GOAL_0] = _scalar(weights[0])
+    if len(goals) > 1:
+        p[abi.P_ANGLE_GOAL_1:abi.P_ANGLE_GOAL_1 + 9] = np.asarray(angle, dtype=float).reshape(9)
+        p[abi.P_X_GOAL_1:abi.P_X_GOAL_1 + 3] = np.asarray(goals[1], dtype=float).reshape(-1)[:3]
+        p[abi.P_WEIGHT_GOAL_1] = _scalar(weights[1])
+    if len(goals) > 2:
+        p[abi.P_X_GOAL_2] = _scalar(goals[2])
+        p[abi.P_WEIGHT_GOAL_2] = _scalar(weights[2])
+    if constraint is not None:
+        p[abi.P_CONSTRAINT_0:abi.P_CONSTRAINT_0 + 4] = np.asarray(constraint, dtype=float).reshape(4)
+    rb = [_scalar(r) for r in radius_bodies]
+    p[abi.P_RADIUS_BODY:abi.P_RADIUS_BODY + len(rb)] = rb
+    return p
+
+
+class ForwardFabricsPlanner:
+    """Joint-space Rollout Fabrics (FPJ:12-336).  `planners` are this package's ParameterizedFabricPlanner objects
+    built by set_planner_panda-style code; their mounts, leaf strings and limits define the rollout handle."""
+
+    def __init__(self, params, planners, N_steps, fk_dict, goal_struct_robots, ROLLOUTS_PLOTTING=0,
+                 goal_estimate_mask=None):
+        self.ROLLOUTS_PLOTTING = ROLLOUTS_PLOTTING
+        self.N_horizon = params.N_HORIZON
+        self.dt = params.dt
+        self.dof = params.dof
+        self.nr_robots = len(self.dof)
+        self.planners = planners
+        self.N_steps = N_steps
+        self.fk_dict = fk_dict
+        self.collision_links_nrs = params.collision_links_nrs
+        self.goal_struct_robots = goal_struct_robots
+        self.fabrics_mode = params.fabrics_mode
+        self.other_robot_static_dynamic = params.STATIC_OR_DYN_FABRICS
+        self.r_robots = params.r_robots
+        self.nr_constraints = params.nr_constraints
+        self.rotation_matrices_pandas = params.rotation_matrix_pandas
+        self.nr_subgoals = [len(g._config) for g in goal_struct_robots]
+        # radius bodies of the active ego links only (FPJ:37-40)
+        self.r_robots_args = [[r for z, r in zip(self.collision_links_nrs[i], self.r_robots[i]) if z > 2]
+                              for i in range(self.nr_robots)]
+        # RF-CV: which robots roll out towards an estimated goal (the reference rewrites robot 1's goal on the
+        # host, EXJ:346-348; with a mask the estimate x_ee + 0.2 v_ee is taken on the device instead)
+        self.goal_estimate_mask = 0 if goal_estimate_mask is None else int(goal_estimate_mask)
+        self._handle = None
+
+    # -- construction ------------------------------------------------------------------------------------------
+    def forward_multi_fabrics_symbolic(self):
+        if self.fabrics_mode != "vel":
+            raise NotImplementedError("the joint-space rollout is defined for fabrics_mode 'vel' only (FPJ:233)")
+        N = self.nr_robots
+        p0 = self.planners[0]
+        if any(p._strings != p0._strings for p in self.planners):
+            raise NotImplementedError("all robots of one rollout share their leaf strings")
+        cfg = _config.panda_config(n_robots=N, horizon=self.N_horizon, dynamic=1 if self.other_robot_static_dynamic else 0,
+                                   mounts=[p._forward_kinematics.mount for p in self.planners], **p0._strings)
+        comp = p0._components
+        cfg.n_ego, cfg.n_planes, cfg.n_goals = comp["n_ego"], comp["n_planes"], comp["n_goals"]
+        cfg.use_limits = 0 if comp["limits"] is None else 1
+        if comp["limits"] is not None:
+            for j in range(7):
+                cfg.limits[j][0], cfg.limits[j][1] = comp["limits"][j]
+        cfg.dt = self.dt
+        links = list(self.collision_links_nrs[0])
+        if any(list(c) != links for c in self.collision_links_nrs):
+            raise NotImplementedError("all robots of one rollout share their sphere table")
+        _config.set_spheres(cfg, links, None, self.r_robots[0])
+        cfg.goal_estimate_mask = self.goal_estimate_mask
+        for key, val in p0.constants.items():
+            setattr(cfg, key, val)
+        from .runtime import FabricHandle
+        self.config = cfg
+        self._handle = FabricHandle(cfg, 0)
+        return {}
+
+    # -- argument marshalling (FPJ:303-329) ------------------------------------------------------------------------
+    def _rows(self, inputs_action):
+        N = self.nr_robots
+        q = np.zeros((7, N))
+        qd = np.zeros((7, N))
+        prm = np.zeros((abi.NPARAM, N))
+        for i in range(N):
+            q[:, i] = np.asarray(inputs_action["q_robots"][i], dtype=float).reshape(-1)[:7]
+            qd[:, i] = np.asarray(inputs_action["q_dot_robots"][i], dtype=float).reshape(-1)[:7]
+            ns = self.nr_subgoals[i]
+            weights = [inputs_action["weight_goals" + str(g)][i] for g in range(ns)]
+            goals = [inputs_action["x_goals" + str(g)][i] for g in range(ns)]
+            con = inputs_action["constraints"][i] if self.nr_constraints[i] else None
+            prm[:, i] = _params_row(self.rotation_matrices_pandas[i], con, weights, goals, self.r_robots_args[i])
+        return q, qd, prm
+
+    def _run(self, inputs_action, traj):
+        if self._handle is None:
+            raise RuntimeError("call forward_multi_fabrics_symbolic() first")
+        h = self._handle
+        q, qd, prm = self._rows(inputs_action)
+        return h.rollout(h.tensor(q), h.tensor(qd), h.tensor(prm), want_traj=traj)
+
+    # -- the reference's entry points --------------------------------------------------------------------------------
+    def get_velocity_rollouts(self, inputs_action):
+        """-> list over robots of np.ndarray shape (1,): mean squared joint velocity over the horizon (FPJ:298-336)."""
+        avg = self._run(inputs_action, traj=False).cpu().numpy().astype(np.float64)
+        return [avg[i:i + 1].copy() for i in range(self.nr_robots)]
+
+    def rollouts_numerical(self, inputs_action=None, **_ignored):
+        """-> (q_N, q_dot_N, q_ddot_N): dicts 'robot_i' -> [ndarray(7, H)] (FPJ:338-423; q_ddot is zero, FPJ:202)."""
+        avg, tq, tqd = self._run(inputs_action, traj=True)
+        tq, tqd = tq.cpu().numpy(), tqd.cpu().numpy()         # [H, 7, N]
+        qN, qdN, qddN = {}, {}, {}
+        for i in range(self.nr_robots):
+            qN["robot_%d" % i] = [tq[:, :, i].T.copy()]
+            qdN["robot_%d" % i] = [tqd[:, :, i].T.copy()]
+            qddN["robot_%d" % i] = [np.zeros_like(tq[:, :, i].T)]
+        return qN, qdN, qddN
+
+    def compute_velocity_average(self, q_dot_robots_N):
+        """FPJ:102-116 on numeric trajectories: sum of squares / (H * dof) per robot."""
+        out = []
+        for i in range(self.nr_robots):
+            traj = q_dot_robots_N["robot_%d" % i]
+            arr = np.asarray(traj[0] if isinstance(traj, list) and np.ndim(traj[0]) == 2 else traj, dtype=float)
+            out.append(float((arr ** 2).sum() / (self.N_horizon * self.dof[i])))
+        return out
+
+    def system_step(self, pos, vel, action, i_robot, dt):
+        """FPJ:72-80."""
+        if self.fabrics_mode == "acc":
+            return pos + dt * vel + 0.5 * dt ** 2 * action, vel + dt * action
+        return pos + dt * action, action
+
+    # -- batched form --------------------------------------------------------------------------------------------------
+    def get_velocity_rollouts_batch(self, q, qdot, params, want_traj=False, stream=None):
+        """Device tensors [7, B*N], [7, B*N], [29, B*N] (row = scenario*N + robot) -> avg_vel [B*N] (, traj_q, traj_qdot)."""
+        return self._handle.rollout(q, qdot, params, want_traj=want_traj, stream=stream)
+
+
+class FabricsRollouts:
+    """Cartesian constant-velocity Rollout Fabrics (FPC:8-563), one instance per robot as in EXC:172-192."""
+
+    def __init__(self, N, dt, nx, nu, dof, nr_obsts, bool_ring, nr_obsts_dyn=0, v_obsts_dyn=(), fabrics_mode="acc",
+                 collision_links_nrs=(7,), nr_constraints=0, radius_sphere=0.08, constraints=None, nr_goals=3):
+        self.N = N
+        self.dt = dt
+        self.Ts = dt
+        self.nx, self.nu, self.dof = nx, nu, dof
+        self.ring = bool_ring
+        self.nr_obsts = nr_obsts
+        self.nr_goals = nr_goals
+        self.nr_obsts_dyn = nr_obsts_dyn
+        self.v_obsts_dyn = list(v_obsts_dyn)
+        self.a_obsts_dyn = [np.zeros((3,))] * len(self.v_obsts_dyn)
+        self.fabrics_mode = fabrics_mode
+        self.collision_links_nrs = list(collision_links_nrs)
+        self.nr_constraints = nr_constraints
+        self.radius_sphere = radius_sphere
+        self.rotation_matrix_panda = np.array([[0, 0, -1], [0, 1, 0], [1, 0, 0]])
+        self.radius_obsts_dyn = []
+        self.radius_obsts = []
+        self.constraints = constraints
+        self.radius_body_panda_links = {str(l): np.array(radius_sphere) for l in self.collision_links_nrs if l > 2}
+        self._handle = None
+
+    def preset_radii_obsts_dyn(self, radii_obst_dyn):
+        self.radius_obsts_dyn = radii_obst_dyn
+
+    def reset_v_obsts_dyn(self, v_obsts_dyn):
+        self.v_obsts_dyn = v_obsts_dyn
+
+    def system_step(self, pos, vel, input, dt, fabrics_mode="vel"):
+        """FPC:77-92."""
+        if fabrics_mode == "acc":
+            return pos + dt * vel + 0.5 * dt ** 2 * input, vel + dt * input
+        if fabrics_mode == "vel":
+            return pos + dt * input, input
+        raise ValueError("nonexisting fabrics mode inserted, should be vel or acc")
+
+    def symbolic_forward_fabrics(self, planner, goal_struct):
+        """Binds the rollout to `planner`'s configuration with horizon N (FPC:347-489)."""
+        self.nr_subgoals = len(goal_struct._config)
+        cfg = planner.config.copy()
+        cfg.horizon = self.N
+        cfg.dt = self.dt
+        cfg.mode = abi.MODE_VEL if self.fabrics_mode == "vel" else abi.MODE_ACC
+        from .runtime import FabricHandle
+        self.config = cfg
+        self._planner = planner
+        self._handle = FabricHandle(cfg, 0)
+        return {}
+
+    def define_arguments_numerical(self, q_robot, q_dot_robot, weight_goals, x_goals, x_obsts, x_obsts_dyn, v_obsts_dyn,
+                                   constraints=()):
+        """Same positional list as FPC:507-536 (angle, constraints, q, q_dot, weights, goals, static x/r, body radii,
+        dynamic radii, dynamic x, v, a)."""
+        arguments = []
+        if self.nr_subgoals > 1:
+            arguments.append(self.rotation_matrix_panda)
+        for _ in range(self.nr_constraints):
+            arguments.append(constraints)
+        arguments.append(q_robot)
+        arguments.append(q_dot_robot)
+        for g in range(self.nr_subgoals):
+            arguments.append(weight_goals["subgoal" + str(g)])
+        for g in range(self.nr_subgoals):
+            arguments.append(x_goals["subgoal" + str(g)])
+        for j in range(self.nr_obsts):
+            arguments.append(x_obsts[j])
+        for j in range(self.nr_obsts):
+            arguments.append(self.radius_obsts[j])
+        if self.nr_obsts + self.nr_obsts_dyn > 0:
+            arguments.extend(self.radius_body_panda_links.values())
+        arguments.extend(self.radius_obsts_dyn)
+        for j in range(self.nr_obsts_dyn):
+            arguments.append(x_obsts_dyn[j])
+        for j in range(self.nr_obsts_dyn):
+            arguments.append(v_obsts_dyn[j])
+        for j in range(self.nr_obsts_dyn):
+            arguments.append(self.a_obsts_dyn[j] if j < len(self.a_obsts_dyn) else np.zeros(3))
+        self.arguments = arguments
+        return arguments
+
+    def _unpack(self, arguments):
+        a = list(arguments)
+        k = 0
+        angle = None
+        if self.nr_subgoals > 1:
+            angle = a[k]; k += 1
+        con = None
+        for _ in range(self.nr_constraints):
+            con = a[k]; k += 1
+        q, qd = a[k], a[k + 1]; k += 2
+        weights = a[k:k + self.nr_subgoals]; k += self.nr_subgoals
+        goals = a[k:k + self.nr_subgoals]; k += self.nr_subgoals
+        xs = a[k:k + self.nr_obsts]; k += self.nr_obsts
+        rs = a[k:k + self.nr_obsts]; k += self.nr_obsts
+        nb = len(self.radius_body_panda_links) if self.nr_obsts + self.nr_obsts_dyn > 0 else 0
+        rb = a[k:k + nb]; k += nb
+        nd = self.nr_obsts_dyn
+        rd = a[k:k + nd]; k += nd
+        xd = a[k:k + nd]; k += nd
+        vd = a[k:k + nd]; k += nd
+        ad = a[k:k + nd]; k += nd
+        if k != len(a):
+            raise TypeError(f"expected {k} rollout arguments, got {len(a)}")
+        if len(rb) not in (0, 6):
+            raise NotImplementedError("the kernels carry ego leaves on links 3..8 (all) or none")
+        prm = _params_row(angle, con, weights, goals, rb if rb else [self.radius_sphere] * 6)
+        M = self.nr_obsts + nd
+        ox, ov, oa, orad = np.zeros((M, 3)), np.zeros((M, 3)), np.zeros((M, 3)), np.zeros(M)
+        for j in range(self.nr_obsts):
+            ox[j] = np.asarray(xs[j], dtype=float).reshape(-1)[:3]
+            orad[j] = _scalar(rs[j])
+        for j in range(nd):
+            r = self.nr_obsts + j
+            ox[r] = np.asarray(xd[j], dtype=float).reshape(-1)[:3]
+            ov[r] = np.asarray(vd[j], dtype=float).reshape(-1)[:3]
+            oa[r] = np.asarray(ad[j], dtype=float).reshape(-1)[:3]
+            orad[r] = _scalar(rd[j])
+        return (np.asarray(q, dtype=float).reshape(-1)[:7], np.asarray(qd, dtype=float).reshape(-1)[:7], prm, ox, ov, oa, orad)
+
+    def _run(self, arguments, traj):
+        if self._handle is None:
+            raise RuntimeError("call symbolic_forward_fabrics() first")
+        h = self._handle
+        q, qd, prm, ox, ov, oa, orad = self._unpack(arguments)
+        t = h.tensor
+        if ox.shape[0]:
+            obst = (t(ox[:, :, None]), t(ov[:, :, None]), t(oa[:, :, None]), t(orad[:, None]))
+        else:
+            obst = (None, None, None, None)
+        return h.rollout_cartesian(t(q[:, None]), t(qd[:, None]), t(prm[:, None]), *obst, want_traj=traj,
+                                   n_static=self.nr_obsts)
+
+    def get_velocity_rollouts(self, arguments):
+        """-> DM-like array of shape (1,) whose .full() is (1,1), as `avg_vel_fun(*arguments)` (FPC:561-563)."""
+        return DM(self._run(arguments, traj=False).cpu().numpy().astype(np.float64))
+
+    def rollouts_numerical(self, arguments):
+        """-> q_N, q_dot_N, q_ddot_N each ndarray (7, H) (FPC:538-559; q_ddot is zero in mode 'vel', FPC:431)."""
+        avg, tq, tqd = self._run(arguments, traj=True)
+        tq, tqd = tq.cpu().numpy()[:, :, 0].T.copy(), tqd.cpu().numpy()[:, :, 0].T.copy()
+        if self.fabrics_mode == "vel":
+            return tq, tqd, np.zeros_like(tq)
+        qdd = np.diff(np.concatenate([np.asarray(self._unpack(arguments)[1])[:, None], tqd], axis=1), axis=1) / self.dt
+        return tq, tqd, qdd
+
+    def x_obsts_dyn_numerical(self, pos_obsts_dyn):
+        """Obstacle positions after each step, x += dt*v (FPC:448-453,491-505): list over k of (3, n_obst) arrays."""
+        x = np.stack([np.asarray(p, dtype=float).reshape(-1)[:3] for p in pos_obsts_dyn]) if len(pos_obsts_dyn) else np.zeros((0, 3))
+        v = np.stack([np.asarray(p, dtype=float).reshape(-1)[:3] for p in self.v_obsts_dyn]) if len(pos_obsts_dyn) else np.zeros((0, 3))
+        out = []
+        for _ in range(self.N):
+            x = x + self.dt * v
+            out.append(x.T.copy())
+        return out
+
+    def compute_velocity_average(self, q_dot_N):
+        """FPC:276-288 on a numeric (7, H) trajectory."""
+        arr = np.asarray(q_dot_N, dtype=float)
+        return [float((arr ** 2).sum() / (self.N * self.dof))]
+
+    def get_velocity_rollouts_batch(self, q, qdot, params, obst_x0, obst_v, obst_a, obst_r, want_traj=False, stream=None):
+        return self._handle.rollout_cartesian(q, qdot, params, obst_x0, obst_v, obst_a, obst_r, want_traj=want_traj,
+                                              n_static=self.nr_obsts, stream=stream)

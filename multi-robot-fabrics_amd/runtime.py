@@ -75,15 +75,16 @@ class FabricHandle:
 
     # ------------------------------------------------------------------ entry points
     def compute_action(self, q, qdot, params, obst_x=None, obst_v=None, obst_a=None, obst_r=None,
-                       want_qddot=False, stream=None):
-        """q,qdot [dof,rows]; params [29,rows]; obst_x/v/a [M,3,rows]; obst_r [M,rows] -> action [dof,rows]."""
+                       want_qddot=False, n_static=0, stream=None):
+        """q,qdot [dof,rows]; params [29,rows]; obst_x/v/a [M,3,rows]; obst_r [M,rows] -> action [dof,rows].
+        The first n_static obstacles are static leaves (3-D, no motion), the rest dynamic leaves."""
         rows = q.shape[1]
         M = 0 if obst_x is None else obst_x.shape[0]
         act = torch.empty((self.dof, rows), dtype=self.dtype, device=self.device)
         qdd = torch.empty_like(act) if want_qddot else None
         rc = self.lib.mrf_compute_action(
             self._h, rows, self._arg(q, (self.dof, rows), "q"), self._arg(qdot, (self.dof, rows), "qdot"),
-            self._arg(params, (abi.NPARAM, rows), "params"), M, self._arg(obst_x, (M, 3, rows), "obst_x"),
+            self._arg(params, (abi.NPARAM, rows), "params"), M, n_static, self._arg(obst_x, (M, 3, rows), "obst_x"),
             self._arg(obst_v, (M, 3, rows), "obst_v"), self._arg(obst_a, (M, 3, rows), "obst_a"),
             self._arg(obst_r, (M, rows), "obst_r"), self._arg(qdd), self._arg(act), self._stream(stream))
         self._check(rc)
@@ -105,7 +106,8 @@ class FabricHandle:
         self._check(rc)
         return (avg, tq, tqd) if want_traj else avg
 
-    def rollout_cartesian(self, q0, qdot0, params, obst_x0, obst_v, obst_a, obst_r, want_traj=False, stream=None):
+    def rollout_cartesian(self, q0, qdot0, params, obst_x0, obst_v, obst_a, obst_r, want_traj=False, n_static=0,
+                          stream=None):
         rows = q0.shape[1]
         H = self.cfg.horizon
         M = 0 if obst_x0 is None else obst_x0.shape[0]
@@ -114,7 +116,7 @@ class FabricHandle:
         tqd = torch.empty_like(tq) if want_traj else None
         rc = self.lib.mrf_rollout_cartesian(
             self._h, rows, self._arg(q0, (self.dof, rows), "q0"), self._arg(qdot0, (self.dof, rows), "qdot0"),
-            self._arg(params, (abi.NPARAM, rows), "params"), M, self._arg(obst_x0, (M, 3, rows), "obst_x0"),
+            self._arg(params, (abi.NPARAM, rows), "params"), M, n_static, self._arg(obst_x0, (M, 3, rows), "obst_x0"),
             self._arg(obst_v, (M, 3, rows), "obst_v"), self._arg(obst_a, (M, 3, rows), "obst_a"),
             self._arg(obst_r, (M, rows), "obst_r"), self._arg(avg), self._arg(tq), self._arg(tqd),
             self._stream(stream))

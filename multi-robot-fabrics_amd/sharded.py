@@ -1,0 +1,148 @@
+"""Robot-sharded Rollout Fabrics: one robot (or a contiguous group of robots) per GPU, with an all-gather of the
+predicted collision-sphere states after every rollout step (the exchange step is FPJ:211-225).
+
+    world = G x D    G ranks share the robots of a scenario (G = largest divisor of world that is <= N),
+                     D data-parallel replicas of that group split the scenario batch.
+    per rollout step on every rank:
+        mrf_step_predict   q += dt*qdot for the owned robots; their spheres (x, v, a) -> sph_own [cnt, S, 9, B]
+        all_gather         over the G ranks of the replica (RCCL over xGMI on GPUs; gloo in the CPU tests)
+        mrf_step_action    fabric solve of the owned robots against everybody else's spheres; qdot := action
+
+The collective moves S*9*B scalars per owned robot per step (B=1: 576 B in f64), so at small B it is latency-bound;
+batching scenarios is what makes the link time matter.  The compute backend is injectable so that the
+partitioning / gather logic is testable on CPU ranks (tests pass an oracle-backed stand-in); the default backend
+is the HIP kernels and there is no CPU fallback.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import abi
+
+
+def robot_groups(n_robots, world):
+    """-> (G, D): ranks per scenario group and number of data-parallel replicas."""
+    G = max(g for g in range(1, min(world, n_robots) + 1) if world % g == 0)
+    return G, world // G
+
+
+def robot_partition(n_robots, G):
+    """Contiguous robot blocks per group rank: list of (first, count); counts differ by at most one."""
+    base, extra = divmod(n_robots, G)
+    out, first = [], 0
+    for g in range(G):
+        cnt = base + (1 if g < extra else 0)
+        out.append((first, cnt))
+        first += cnt
+    return out
+
+
+class HipStepBackend:
+    def __init__(self, cfg, device_index):
+        from .runtime import FabricHandle
+        self.h = FabricHandle(cfg, device_index)
+        self.dtype, self.device = self.h.dtype, self.h.device
+
+    def predict(self, n_scen, first, count, q_io, qd, sph_own):
+        self.h.step_predict(n_scen, first, count, q_io, qd, sph_own)
+
+    def action(self, n_scen, first, count, q, qd_io, prm, sph_all, sumsq):
+        self.h.step_action(n_scen, first, count, q, qd_io, prm, sph_all, sumsq)
+
+
+class ShardedRollout:
+    def __init__(self, cfg, rank, world, backend=None, device_index=0):
+        self.cfg = cfg.copy()
+        self.N, self.S, self.H = cfg.n_robots, cfg.n_spheres, cfg.horizon
+        self.rank, self.world = rank, world
+        self.G, self.D = robot_groups(self.N, world)
+        self.replica, self.grank = divmod(rank, self.G)
+        self.parts = robot_partition(self.N, self.G)
+        self.first, self.count = self.parts[self.grank]
+        self.cnt_max = max(c for _, c in self.parts)
+        self.uniform = all(c == self.cnt_max for _, c in self.parts)
+        self.backend = backend if backend is not None else HipStepBackend(cfg, device_index)
+        self.dtype, self.device = self.backend.dtype, self.backend.device
+        self.group = None
+        if world > 1:
+            # one communicator per replica; every rank must take part in every new_group call
+            for d in range(self.D):
+                ranks = list(range(d * self.G, (d + 1) * self.G))
+                g = dist.new_group(ranks=ranks) if self.G > 1 else None
+                if d == self.replica:
+                    self.group = g
+        if not self.uniform:
+            # scatter plan from the padded gather buffer [G, cnt_max] to robots [N]
+            idx = []
+            for g, (f, c) in enumerate(self.parts):
+                idx += [g * self.cnt_max + l for l in range(c)]
+            self._unpad = torch.tensor(idx, device=self.device)
+
+    def own_rows(self, n_scen):
+        """Global row indices (scenario*N + robot) of the rows this rank owns, in its local row order."""
+        s = torch.arange(n_scen).repeat_interleave(self.count)
+        r = torch.arange(self.first, self.first + self.count).repeat(n_scen)
+        return s * self.N + r
+
+    def rollout(self, q, qd, prm):
+        """q, qd [7, B*count], prm [29, B*count] for the owned robots (local row = scenario*count + l).
+        Advances q, qd in place over the horizon; returns avg_vel [B*count]."""
+        n_scen = q.shape[1] // self.count
+        S, H = self.S, self.H
+        sph_pad = torch.zeros((self.G, self.cnt_max, S, 9, n_scen), dtype=self.dtype, device=self.device)
+        sph_own = sph_pad[self.grank] if self.G == 1 else torch.zeros((self.cnt_max, S, 9, n_scen), dtype=self.dtype,
+                                                                        device=self.device)
+        sumsq = torch.zeros((n_scen * self.count,), dtype=self.dtype, device=self.device)
+        for _ in range(H):
+            self.backend.predict(n_scen, self.first, self.count, q, qd, sph_own[:self.count])
+            if self.G > 1:
+                dist.all_gather_into_tensor(sph_pad.view(-1), sph_own.view(-1), group=self.group)
+            sph_all = sph_pad.view(self.G * self.cnt_max, S, 9, n_scen)
+            if not self.uniform:
+                sph_all = sph_all.index_select(0, self._unpad)
+            self.backend.action(n_scen, self.first, self.count, q, qd, prm, sph_all, sumsq)
+        return sumsq / (H * 7)
+
+    # ------------------------------------------------------------------ bench leg (bench.py --shard robots)
+    @staticmethod
+    def bench(cfg, batch, args, rank, world, local_rank):
+        import numpy as np
+        sr = ShardedRollout(cfg, rank, world, device_index=local_rank)
+        B = args.scenarios
+        rows = sr.own_rows(B).numpy()
+        h = sr.backend.h
+        q0, qd0, prm = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            sr.rollout(q0.clone(), qd0.clone(), prm)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            avg = sr.rollout(q0.clone(), qd0.clone(), prm)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.isfinite(avg).all()
+        N, H, S = cfg.n_robots, cfg.horizon, cfg.n_spheres
+        sb = 8 if cfg.scalar == abi.F64 else 4
+        rate = sr.D * B * args.steps / elapsed
+        return {
+            "metric": f"rollout control-steps/s, {N}-Panda RF-CV H={H}, robots sharded over GPUs with per-step all-gather",
+            "value": rate, "unit": "control-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{N}-Panda RF-CV H={H} coupled rollout only", "scenarios_per_replica": B,
+                       "robot_group_ranks": sr.G, "replicas": sr.D, "robots_per_rank": [c for _, c in sr.parts],
+                       "sharding": "robots (all-gather of S*9*B sphere scalars per robot per rollout step)"},
+            "rollout_steps_per_s": rate * N * H,
+            "allgather_bytes_per_rank_per_step": sr.cnt_max * S * 9 * B * sb,
+        }

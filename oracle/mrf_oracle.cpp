@@ -265,6 +265,7 @@ void pull_add(QSpec& S, int n, int d, const double M[3][3], const double* f, con
 
 struct Obst {
   double x[3], v[3], a[3], r;
+  bool is_static = false;
 };
 
 // spherical obstacle leaf, the 3-stage pull of `fabrics` (geometry map, dynamic map, fk):
@@ -273,7 +274,7 @@ struct Obst {
 //   dyn. pull   x_rel = p - x_ref                 f -= M xdd_ref
 //   pull 2      through fk p(q)
 void obstacle_leaf(const mrf_config& cfg, QSpec& S, int n, const PointKin& K, double r_body, const Obst& o) {
-  int d = cfg.obst_dim;
+  int d = o.is_static ? 3 : cfg.obst_dim;  // static spheres: 3-D distance; dynamic: dynamic_obstacle_dimension
   double xr[3] = {0, 0, 0}, vr[3] = {0, 0, 0};
   double nn = 0, vv = 0;
   for (int i = 0; i < d; ++i) {
@@ -495,7 +496,7 @@ int mrfo_set_threads(int n) {
 
 // Same array layouts as include/mrf.h, host pointers, double only.
 int mrfo_compute_action(const mrf_config* cfg, int64_t rows, const double* q, const double* qdot, const double* params,
-                        int32_t n_obst, const double* ox, const double* ov, const double* oa, const double* orad,
+                        int32_t n_obst, int32_t n_static, const double* ox, const double* ov, const double* oa, const double* orad,
                         double* qddot_out, double* action_out) {
   const int n = dof_of(*cfg);
 #pragma omp parallel for schedule(static)
@@ -514,6 +515,9 @@ int mrfo_compute_action(const mrf_config* cfg, int64_t rows, const double* q, co
         obst[m].a[c] = oa ? oa[(m * 3 + c) * rows + r] : 0.0;
       }
       obst[m].r = orad[m * rows + r];
+      obst[m].is_static = m < n_static;
+      if (obst[m].is_static)
+        for (int c = 0; c < 3; ++c) obst[m].v[c] = obst[m].a[c] = 0.0;
     }
     Row row{qv, qdv, prm};
     solve_fabric(*cfg, (int)(r % cfg->n_robots), row, obst, qdd, act);
@@ -527,7 +531,7 @@ int mrfo_compute_action(const mrf_config* cfg, int64_t rows, const double* q, co
 
 // geometry / forced (M, f) of one row, for per-leaf-level debugging against the autodiff oracle
 int mrfo_specs(const mrf_config* cfg, int32_t robot, const double* q, const double* qdot, const double* params,
-               int32_t n_obst, const double* ox, const double* ov, const double* oa, const double* orad, double* Mg,
+               int32_t n_obst, int32_t n_static, const double* ox, const double* ov, const double* oa, const double* orad, double* Mg,
                double* fg, double* Mf, double* ff) {
   std::vector<Obst> obst(n_obst);
   for (int m = 0; m < n_obst; ++m) {
@@ -537,6 +541,9 @@ int mrfo_specs(const mrf_config* cfg, int32_t robot, const double* q, const doub
       obst[m].a[c] = oa ? oa[m * 3 + c] : 0.0;
     }
     obst[m].r = orad[m];
+    obst[m].is_static = m < n_static;
+    if (obst[m].is_static)
+      for (int c = 0; c < 3; ++c) obst[m].v[c] = obst[m].a[c] = 0.0;
   }
   double qdd[DOF_MAX], act[DOF_MAX];
   QSpec g, f;
@@ -648,7 +655,7 @@ int mrfo_rollout(const mrf_config* cfg, int64_t n_scen, const double* q0, const 
 // Cartesian constant-velocity rollout, forward_planner_Cartesian.py:421-458: action first, then the
 // system step, then every obstacle x += dt * v.
 int mrfo_rollout_cartesian(const mrf_config* cfg, int64_t rows, const double* q0, const double* qdot0,
-                           const double* params, int32_t n_obst, const double* ox0, const double* ov, const double* oa,
+                           const double* params, int32_t n_obst, int32_t n_static, const double* ox0, const double* ov, const double* oa,
                            const double* orad, double* avg_out, double* traj_q, double* traj_qd) {
   const int n = dof_of(*cfg), H = cfg->horizon;
 #pragma omp parallel for schedule(static)
@@ -663,10 +670,11 @@ int mrfo_rollout_cartesian(const mrf_config* cfg, int64_t rows, const double* q0
     for (int m = 0; m < n_obst; ++m) {
       for (int c = 0; c < 3; ++c) {
         obst[m].x[c] = ox0[(m * 3 + c) * rows + r];
-        obst[m].v[c] = ov[(m * 3 + c) * rows + r];
-        obst[m].a[c] = oa ? oa[(m * 3 + c) * rows + r] : 0.0;
+        obst[m].v[c] = (ov && m >= n_static) ? ov[(m * 3 + c) * rows + r] : 0.0;
+        obst[m].a[c] = (oa && m >= n_static) ? oa[(m * 3 + c) * rows + r] : 0.0;
       }
       obst[m].r = orad[m * rows + r];
+      obst[m].is_static = m < n_static;
     }
     double sumsq = 0;
     for (int k = 0; k < H; ++k) {

@@ -43,7 +43,7 @@ def dof(cfg):
     return 7 if cfg.model == abi.MODEL_PANDA7 else 3
 
 
-def compute_action(cfg, q, qdot, params, ox=None, ov=None, oa=None, orad=None):
+def compute_action(cfg, q, qdot, params, ox=None, ov=None, oa=None, orad=None, n_static=0):
     """q,qdot [dof][rows]; params [29][rows]; ox/ov/oa [M][3][rows]; orad [M][rows] -> (qddot, action)."""
     q, qdot, params = _f64(q), _f64(qdot), _f64(params)
     rows = q.shape[1]
@@ -51,19 +51,19 @@ def compute_action(cfg, q, qdot, params, ox=None, ov=None, oa=None, orad=None):
     ox, ov, oa, orad = _f64(ox), _f64(ov), _f64(oa), _f64(orad)
     qdd = np.zeros_like(q)
     act = np.zeros_like(q)
-    rc = lib().mrfo_compute_action(C.byref(cfg), C.c_int64(rows), _p(q), _p(qdot), _p(params), C.c_int32(M),
+    rc = lib().mrfo_compute_action(C.byref(cfg), C.c_int64(rows), _p(q), _p(qdot), _p(params), C.c_int32(M), C.c_int32(n_static),
                                    _p(ox), _p(ov), _p(oa), _p(orad), _p(qdd), _p(act))
     assert rc == 0
     return qdd, act
 
 
-def specs(cfg, robot, q, qdot, params, ox=None, ov=None, oa=None, orad=None):
+def specs(cfg, robot, q, qdot, params, ox=None, ov=None, oa=None, orad=None, n_static=0):
     q, qdot, params = _f64(q), _f64(qdot), _f64(params)
     M = 0 if ox is None else len(ox)
     ox, ov, oa, orad = _f64(ox), _f64(ov), _f64(oa), _f64(orad)
     Mg, Mf = np.zeros((7, 7)), np.zeros((7, 7))
     fg, ff = np.zeros(7), np.zeros(7)
-    rc = lib().mrfo_specs(C.byref(cfg), C.c_int32(robot), _p(q), _p(qdot), _p(params), C.c_int32(M), _p(ox), _p(ov),
+    rc = lib().mrfo_specs(C.byref(cfg), C.c_int32(robot), _p(q), _p(qdot), _p(params), C.c_int32(M), C.c_int32(n_static), _p(ox), _p(ov),
                           _p(oa), _p(orad), _p(Mg), _p(fg), _p(Mf), _p(ff))
     assert rc == 0
     return Mg, fg, Mf, ff
@@ -93,7 +93,7 @@ def rollout(cfg, q0, qdot0, params, traj=False):
     return avg, tq, tqd
 
 
-def rollout_cartesian(cfg, q0, qdot0, params, ox0, ov, oa, orad, traj=False):
+def rollout_cartesian(cfg, q0, qdot0, params, ox0, ov, oa, orad, traj=False, n_static=0):
     q0, qdot0, params = _f64(q0), _f64(qdot0), _f64(params)
     ox0, ov, oa, orad = _f64(ox0), _f64(ov), _f64(oa), _f64(orad)
     rows = q0.shape[1]
@@ -102,7 +102,7 @@ def rollout_cartesian(cfg, q0, qdot0, params, ox0, ov, oa, orad, traj=False):
     avg = np.zeros(rows)
     tq = np.zeros((H, n, rows)) if traj else None
     tqd = np.zeros((H, n, rows)) if traj else None
-    rc = lib().mrfo_rollout_cartesian(C.byref(cfg), C.c_int64(rows), _p(q0), _p(qdot0), _p(params), C.c_int32(M),
+    rc = lib().mrfo_rollout_cartesian(C.byref(cfg), C.c_int64(rows), _p(q0), _p(qdot0), _p(params), C.c_int32(M), C.c_int32(n_static),
                                       _p(ox0), _p(ov), _p(oa), _p(orad), _p(avg), _p(tq), _p(tqd))
     assert rc == 0
     return avg, tq, tqd

@@ -1,0 +1,299 @@
+"""GPU: the reference-shaped Python surface (planner / rollout / kinematics classes) against the CPU oracle.
+
+These read like the reference's drivers (example_pandas_Jointspace.py:64-193,354-448,
+example_pointmasses_static.py:102-199) with the simulator replaced by seeded states.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.goals import GoalComposition
+from multi_robot_fabrics_amd.kinematics import GenericURDFFk, UtilsKinematics, compute_endeffector
+from multi_robot_fabrics_amd.parameters import manipulator_parameters
+from multi_robot_fabrics_amd.planner import ParameterizedFabricPlanner
+from multi_robot_fabrics_amd.rollouts import FabricsRollouts, ForwardFabricsPlanner
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def create_dummy_goal_panda():
+    return GoalComposition(name="goal", content_dict={
+        "subgoal0": {"weight": 2.0, "is_primary_goal": True, "indices": [0, 1, 2], "parent_link": "world",
+                     "child_link": "panda_hand", "desired_position": [0.1, 0.6, 0.8], "epsilon": 0.05, "type": "staticSubGoal"},
+        "subgoal1": {"weight": 10.0, "is_primary_goal": False, "indices": [0, 1, 2], "parent_link": "panda_link7",
+                     "child_link": "panda_hand", "desired_position": [0.107, 0.0, 0.0], "angle": [-0.366, 0.0, 0.0, 0.3305],
+                     "epsilon": 0.05, "type": "staticSubGoal"},
+        "subgoal2": {"weight": 1.0, "is_primary_goal": False, "indices": [6], "desired_position": [np.pi / 4],
+                     "epsilon": 0.05, "type": "staticJointSpaceSubGoal"}})
+
+
+def set_planner_panda(params, i_robot, nr_obst=0, nr_obst_dyn=1, collision_links_nr=(1, 2, 3, 4, 5, 6, 7, 8)):
+    goal = create_dummy_goal_panda()
+    fk = GenericURDFFk(None, "panda_link0", "panda_leftfinger")
+    planner = ParameterizedFabricPlanner(
+        7, fk,
+        geometry_plane_constraint="10*(1/(1+1*ca.exp(-10*x))-1) * (xdot**2)",
+        collision_geometry="-0.5 / (x ** 4) * (xdot ** 2)",
+        collision_finsler="0.01/(x**4) * xdot**2")
+    planner._forward_kinematics.set_mount_transformation(params.mount_transform[i_robot])
+    planner.set_components(collision_links=["panda_link%d" % l for l in collision_links_nr], goal=goal,
+                           number_obstacles=nr_obst, number_dynamic_obstacles=nr_obst_dyn, dynamic_obstacle_dimension=3,
+                           number_plane_constraints=1, limits=config.PANDA_LIMITS)
+    planner.concretize(mode="vel", time_step=0.01)
+    return planner, goal
+
+
+def _state(params, seed):
+    cfg = config.panda_config(n_robots=params.nr_robots, horizon=params.N_HORIZON, mounts=params.mount_transform)
+    b = scenarios.panda_batch(cfg, 1, seed=seed, x_min=0.08)
+    return cfg, b
+
+
+def test_compute_action_kwargs_like_the_example(oracle):
+    """EXJ:417-448 for both robots, dynamic fabrics, n_obst_per_link = 1."""
+    params = manipulator_parameters(nr_robots=2, n_obst_per_link=1)
+    cfg, b = _state(params, 3)
+    planners = [set_planner_panda(params, i, nr_obst=0, nr_obst_dyn=params.nr_obsts_dyn_all[i])[0] for i in range(2)]
+    sx, sv, sa = oracle.fk_spheres(cfg, b["q"], b["qdot"])
+    for i in range(2):
+        j = 1 - i
+        x_dyn = [sx[s, :, j] for s in range(8)]
+        v_dyn = [sv[s, :, j] for s in range(8)]
+        a_dyn = [np.zeros(3)] * 8                                     # EXJ:411 "currently no acceleration"
+        r_dyn = [params.r_robots[j][s] for s in range(8)]
+        arguments_robot = dict(q=b["q"][:, i], qdot=b["qdot"][:, i], x_goal_0=np.array(b["params"][0:3, i]),
+                               weight_goal_0=2.0, angle_goal_1=params.rotation_matrix_pandas[i],
+                               x_goal_1=np.array([0.107, 0.0, 0.0]), weight_goal_1=20.0, x_goal_2=np.array([np.pi / 4]),
+                               weight_goal_2=1.0, x_obsts=x_dyn, radius_obsts=r_dyn, constraint_0=params.constraints[i],
+                               radius_body_panda_links=params.radius_body_panda_links,
+                               radius_body_panda_hand=np.array([params.radius_sphere]), x_obsts_dynamic=x_dyn,
+                               xdot_obsts_dynamic=v_dyn, xddot_obsts_dynamic=a_dyn, radius_obsts_dynamic=r_dyn)
+        action = planners[i].compute_action(**arguments_robot)
+        assert isinstance(action, np.ndarray) and action.shape == (7,)
+        c1 = config.panda_config(n_robots=1, horizon=1, mounts=[params.mount_transform[i]])
+        _, want = oracle.compute_action(c1, b["q"][:, i:i + 1], b["qdot"][:, i:i + 1], b["params"][:, i:i + 1],
+                                        np.array(x_dyn)[:, :, None], np.array(v_dyn)[:, :, None],
+                                        np.array(a_dyn)[:, :, None], np.array(r_dyn)[:, None])
+        assert np.abs(action - want[:, 0]).max() < 1e-9 * max(1.0, np.abs(want).max())
+        # positional form used by the rollout builders (FPJ:184-185,227-233)
+        keys = planners[i]._funs._input_keys
+        named = dict(arguments_robot)
+        for s in range(8):
+            named[f"x_obst_dynamic_{s}"], named[f"xdot_obst_dynamic_{s}"] = x_dyn[s], v_dyn[s]
+            named[f"xddot_obst_dynamic_{s}"], named[f"radius_obst_dynamic_{s}"] = a_dyn[s], r_dyn[s]
+        for l in range(3, 9):
+            named[f"radius_body_panda_link{l}"] = params.radius_body_panda_links[str(l)]
+        again = planners[i]._funs._function(*[named[k] for k in keys])
+        assert np.array_equal(again, action)
+
+
+def test_static_fabrics_and_grasp_planner(oracle):
+    """STATIC_OR_DYN_FABRICS == 0 builds the planner with static spheres (EXJ:141-146); grasp planner EXJ:160-166."""
+    params = manipulator_parameters(nr_robots=2, n_obst_per_link=1)
+    cfg, b = _state(params, 4)
+    sx, _, _ = oracle.fk_spheres(cfg, b["q"], b["qdot"])
+    planner, _ = set_planner_panda(params, 0, nr_obst=8, nr_obst_dyn=0)
+    grasp, _ = set_planner_panda(params, 0, nr_obst=0, nr_obst_dyn=0, collision_links_nr=())
+    x_dyn = [sx[s, :, 1] for s in range(8)]
+    kw = dict(q=b["q"][:, 0], qdot=b["qdot"][:, 0], x_goal_0=b["params"][0:3, 0], weight_goal_0=2.0,
+              angle_goal_1=params.rotation_matrix_pandas[0], x_goal_1=[0.107, 0, 0], weight_goal_1=20.0,
+              x_goal_2=[np.pi / 4], weight_goal_2=1.0, x_obsts=x_dyn, radius_obsts=[0.08] * 8,
+              constraint_0=params.constraints[0], radius_body_panda_links=params.radius_body_panda_links,
+              x_obsts_dynamic=x_dyn, xdot_obsts_dynamic=[np.ones(3)] * 8, xddot_obsts_dynamic=[np.ones(3)] * 8,
+              radius_obsts_dynamic=[0.08] * 8)
+    c1 = config.panda_config(n_robots=1, horizon=1, mounts=[params.mount_transform[0]])
+    _, want = oracle.compute_action(c1, b["q"][:, :1], b["qdot"][:, :1], b["params"][:, :1], np.array(x_dyn)[:, :, None],
+                                    None, None, np.full((8, 1), 0.08))
+    assert np.abs(planner.compute_action(**kw) - want[:, 0]).max() < 1e-9
+    cg = config.panda_config(n_robots=1, horizon=1, n_ego=0, mounts=[params.mount_transform[0]])
+    _, want_g = oracle.compute_action(cg, b["q"][:, :1], b["qdot"][:, :1], b["params"][:, :1])
+    assert np.abs(grasp.compute_action(**kw) - want_g[:, 0]).max() < 1e-9
+    with pytest.raises(KeyError):
+        planner.compute_action(q=kw["q"], qdot=kw["qdot"])
+
+
+@pytest.mark.parametrize("n_robots,estimate", [(2, False), (3, True)])
+def test_forward_fabrics_planner(oracle, n_robots, estimate):
+    """define_rollout_planners + get_velocity_rollouts + rollouts_numerical (EXJ:172-193,354-375)."""
+    params = manipulator_parameters(nr_robots=n_robots, n_obst_per_link=1)
+    params.define_settings(ROLLOUT_FABRICS=True, STATIC_OR_DYN_FABRICS=1, ESTIMATE_GOAL=estimate, N_HORIZON=6)
+    cfg, b = _state(params, 5)
+    planners, goal_structs = zip(*[set_planner_panda(params, i, nr_obst=params.nr_obsts[i],
+                                                      nr_obst_dyn=params.nr_obsts_dyn[i]) for i in range(n_robots)])
+    mask = ((1 << n_robots) - 2) if estimate else 0
+    fp = ForwardFabricsPlanner(params=params, planners=list(planners), N_steps=100, fk_dict=None,
+                               goal_struct_robots=list(goal_structs), goal_estimate_mask=mask)
+    assert fp.forward_multi_fabrics_symbolic() == {}
+    inputs_action = {"q_robots": [b["q"][:, i] for i in range(n_robots)],
+                     "q_dot_robots": [b["qdot"][:, i] for i in range(n_robots)], "x_obsts": [[] * n_robots],
+                     "x_goals0": [b["params"][0:3, i] for i in range(n_robots)],
+                     "x_goals1": [g._config.subgoal1.desired_position for g in goal_structs],
+                     "x_goals2": [g._config.subgoal2.desired_position for g in goal_structs],
+                     "weight_goals0": [2.0] * n_robots, "weight_goals1": [20.0] * n_robots, "weight_goals2": [1.0] * n_robots,
+                     "constraints": [np.array([0, 0, 1, -params.mount_param["z_table"]])] * n_robots}
+    prm = b["params"].copy()
+    cfg.horizon = 6
+    cfg.goal_estimate_mask = mask
+    want_avg, want_q, want_qd = oracle.rollout(cfg, b["q"], b["qdot"], prm, traj=True)
+    vel_avg = fp.get_velocity_rollouts(inputs_action=inputs_action)
+    assert len(vel_avg) == n_robots and all(v.shape == (1,) for v in vel_avg)
+    assert np.abs(np.concatenate(vel_avg) - want_avg).max() < 1e-9
+    qN, qdN, qddN = fp.rollouts_numerical(inputs_action)
+    for i in range(n_robots):
+        assert qN[f"robot_{i}"][0].shape == (7, 6)
+        assert np.abs(qN[f"robot_{i}"][0] - want_q[:, :, i].T).max() < 1e-9
+        assert np.abs(qdN[f"robot_{i}"][0] - want_qd[:, :, i].T).max() < 1e-9
+        assert not qddN[f"robot_{i}"][0].any()
+    assert np.allclose(fp.compute_velocity_average(qdN), want_avg, rtol=1e-9)
+
+
+def test_fabrics_rollouts_cartesian(oracle):
+    """define_rollout_planners of the Cartesian example (EXC:160-192) and its per-step calls (EXC:363-404)."""
+    params = manipulator_parameters(nr_robots=2, n_obst_per_link=1)
+    params.define_settings(ROLLOUT_FABRICS=True, STATIC_OR_DYN_FABRICS=1, N_HORIZON=5)
+    cfg, b = _state(params, 6)
+    sx, sv, _ = oracle.fk_spheres(cfg, b["q"], b["qdot"])
+    i, j = 0, 1
+    planner, goal = set_planner_panda(params, i, nr_obst=0, nr_obst_dyn=params.nr_obsts_dyn_all[i])
+    fr = FabricsRollouts(N=params.N_HORIZON, dt=params.dt, nx=14, nu=7, dof=7, nr_obsts=params.nr_obsts[i], bool_ring=False,
+                         nr_obsts_dyn=params.nr_obsts_dyn_all[i], v_obsts_dyn=[np.zeros(3)] * 8, fabrics_mode="vel",
+                         collision_links_nrs=params.collision_links_nrs[i], nr_constraints=1, radius_sphere=0.08,
+                         constraints=params.constraints[i], nr_goals=3)
+    fr.symbolic_forward_fabrics(planner=planner, goal_struct=goal)
+    fr.preset_radii_obsts_dyn(params.r_dyns_obsts[i])
+    x_dyn = [sx[s, :, j] for s in range(8)]
+    v_dyn = [sv[s, :, j] for s in range(8)]
+    weight_goals = {"subgoal0": 2.0, "subgoal1": 20.0, "subgoal2": 1.0}
+    x_goals = {"subgoal0": b["params"][0:3, i], "subgoal1": [0.107, 0.0, 0.0], "subgoal2": [np.pi / 4]}
+    arguments = fr.define_arguments_numerical(q_robot=b["q"][:, i], q_dot_robot=b["qdot"][:, i],
+                                              constraints=params.constraints[i], weight_goals=weight_goals,
+                                              x_goals=x_goals, x_obsts=[], x_obsts_dyn=x_dyn, v_obsts_dyn=v_dyn)
+    assert len(arguments) == 1 + 1 + 2 + 3 + 3 + 6 + 8 + 8 * 3
+    c1 = config.panda_config(n_robots=1, horizon=5, mounts=[params.mount_transform[i]])
+    want_avg, want_q, want_qd = oracle.rollout_cartesian(c1, b["q"][:, :1], b["qdot"][:, :1], b["params"][:, :1],
+                                                         np.array(x_dyn)[:, :, None], np.array(v_dyn)[:, :, None],
+                                                         np.zeros((8, 3, 1)), np.full((8, 1), 0.08), traj=True)
+    avg = fr.get_velocity_rollouts(arguments)
+    assert avg.full().shape == (1, 1) and abs(avg.full()[0, 0] - want_avg[0]) < 1e-9
+    qN, qdN, qddN = fr.rollouts_numerical(arguments)
+    assert qN.shape == (7, 5)
+    assert np.abs(qN - want_q[:, :, 0].T).max() < 1e-9 and np.abs(qdN - want_qd[:, :, 0].T).max() < 1e-9
+    xs = fr.x_obsts_dyn_numerical(x_dyn)
+    assert len(xs) == 5 and xs[0].shape == (3, 8)
+
+
+def test_utils_kinematics_functions(oracle):
+    """fk_dict of define_forward_kinematics (utils.py:60-85) and the call pattern of EXJ:331-343, FPJ:91-99."""
+    g = np.load(os.path.join(GOLD, "panda_kinematics.npz"))
+    params = manipulator_parameters(nr_robots=2)
+    uk = UtilsKinematics()
+
+    class _P:          # only the mount is read from a planner here
+        def __init__(self, T):
+            self._forward_kinematics = GenericURDFFk(None, "panda_link0", "panda_leftfinger")
+            self._forward_kinematics.set_mount_transformation(T)
+
+    mounts = [g["mounts"][0], g["mounts"][1]]
+    fk_dict = uk.define_forward_kinematics([_P(m) for m in mounts], params.collision_links_nrs, params.collision_links)
+    assert len(fk_dict["fk_fun"][1]) == 8
+    for i in range(12):                    # the zero-offset golden cases
+        r, link = int(g["robot"][i]), int(g["link"][i])
+        if r > 1:
+            continue
+        q, qd = g["q"][i], g["qd"][i]
+        x = fk_dict["fk_fun"][r][link - 1](q)
+        assert np.abs(x.full().transpose()[0] - g["x"][i]).max() < 1e-12
+        J = fk_dict["jac_fun"][r][link - 1](q)
+        assert np.abs(np.asarray(J) - g["J"][i]).max() < 1e-12
+        v = (J @ qd)
+        assert np.abs(v.full().transpose()[0] - g["v"][i]).max() < 1e-12
+        a = fk_dict["jac_dot_fun"][r][link - 1](q, qd) @ qd
+        assert np.abs(np.asarray(a) - g["a"][i]).max() < 1e-10
+    ee = uk.define_symbolic_endeffector([_P(m) for m in mounts])
+    x_ee, v_ee = compute_endeffector([g["q"][7], g["q"][7]], [g["qd"][7], g["qd"][7]], ee, nr_robots=2)
+    assert x_ee[0].shape == (3,) and v_ee[1].shape == (3,)
+
+
+def test_point_mass_example_static(oracle):
+    """4 point robots, 6 scene spheres + the 3 other robots as static spheres (example_pointmasses_static.py:102-199)."""
+    goal = GoalComposition(name="goal", content_dict={"subgoal0": {
+        "weight": 1, "is_primary_goal": True, "indices": [0, 1], "parent_link": "world", "child_link": "base_link",
+        "desired_position": [1.5, 0.99], "epsilon": 0.1, "type": "staticSubGoal"}})
+    fk = GenericURDFFk(None, "world", "base_link")
+    planner = ParameterizedFabricPlanner(3, fk, collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
+                                         collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
+    planner.set_components(["base_link"], {}, goal=goal, number_obstacles=9)
+    planner.concretize()
+    obstacles_pos = [[1, 1.25, 0], [1, 3.75, 0], [1, -1.25, 0], [-1.1, 0, 0], [-1.1, 2.5, 0], [-1.1, -2.5, 0]]
+    robots_pos = np.array([[-2.5, 0.01, 0.0], [-2.5, -2.49, 0.0], [2.5, 1.26, 0.0], [2.5, 3.74, 0.0]])
+    goal_robots = [np.array([1.5, 3.76]), np.array([1.5, 1.26]), np.array([-2.5, 0.01]), np.array([-2.5, -2.49])]
+    rng = np.random.default_rng(0)
+    vel = rng.uniform(-0.3, 0.3, (4, 3))
+    cfg = config.planar3_config(n_robots=1)
+    for i in range(4):
+        pos_obs = [np.array(o, dtype=float) for o in obstacles_pos] + [robots_pos[j] for j in range(4) if j != i]
+        radius_obs = [1.0] * 6 + [np.array(0.2)] * 3
+        action = planner.compute_action(q=robots_pos[i], qdot=vel[i], x_goal_0=goal_robots[i],
+                                        weight_goal_0=goal.sub_goals()[0].weight(), x_obsts=pos_obs,
+                                        radius_obsts=radius_obs, radius_body_base_link=np.array(0.2))
+        prm = np.zeros((abi.NPARAM, 1))
+        prm[0:2, 0] = goal_robots[i]; prm[abi.P_WEIGHT_GOAL_0] = 1.0; prm[abi.P_RADIUS_BODY] = 0.2
+        _, want = oracle.compute_action(cfg, robots_pos[i][:, None], vel[i][:, None], prm, np.array(pos_obs)[:, :, None],
+                                        None, None, np.array([float(r) for r in radius_obs])[:, None], n_static=9)
+        assert action.shape == (3,) and np.abs(action - want[:, 0]).max() < 1e-9 * max(1.0, np.abs(want).max())
+
+
+def test_point_mass_example_dynamic_matches_golden():
+    """Static scene spheres (3-D) + other robots as 2-D dynamic spheres (example_pointmasses_dynamic.py:102-212)."""
+    g = np.load(os.path.join(GOLD, "planar_actions.npz"))
+    goal = GoalComposition(name="goal", content_dict={"subgoal0": {
+        "weight": 1, "is_primary_goal": True, "indices": [0, 1], "parent_link": "world", "child_link": "base_link",
+        "desired_position": [1.5, 0.99], "epsilon": 0.1, "type": "staticSubGoal"}})
+    for i in np.nonzero(g["n_static"] == 2)[0]:
+        planner = ParameterizedFabricPlanner(3, GenericURDFFk(None, "world", "base_link"),
+                                             collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
+                                             collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
+        planner.set_components(["base_link"], {}, goal=goal, number_obstacles=2, number_dynamic_obstacles=2,
+                               dynamic_obstacle_dimension=2)
+        planner.concretize()
+        action = planner.compute_action(
+            q=g["q"][i], qdot=g["qd"][i], x_goal_0=g["g0"][i], weight_goal_0=1.0, x_obsts=list(g["ox"][i][:2]),
+            radius_obsts=list(g["orad"][i][:2]), radius_body_base_link=np.array(0.2),
+            x_obst_dynamic_0=g["ox"][i][2][:2], xdot_obst_dynamic_0=g["ov"][i][2][:2], xddot_obst_dynamic_0=g["oa"][i][2][:2],
+            radius_obst_dynamic_0=g["orad"][i][2], x_obst_dynamic_1=g["ox"][i][3][:2], xdot_obst_dynamic_1=g["ov"][i][3][:2],
+            xddot_obst_dynamic_1=g["oa"][i][3][:2], radius_obst_dynamic_1=g["orad"][i][3])
+        assert np.abs(action - g["action"][i]).max() < 1e-9 * max(1.0, np.abs(g["action"][i]).max())
+
+
+def test_golden_vectors_on_gpu():
+    """The committed autodiff vectors straight through the planner front-end (no oracle in the loop)."""
+    g = np.load(os.path.join(GOLD, "panda_actions.npz"))
+    R1 = np.array([[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]])
+    for i, kind in enumerate(g["kinds"]):
+        if kind in ("nogoal",):
+            continue
+        fk = GenericURDFFk(None, "panda_link0", "panda_leftfinger")
+        fk.set_mount_transformation(g["mount"][i])
+        planner = ParameterizedFabricPlanner(7, fk, geometry_plane_constraint="10*(1/(1+1*ca.exp(-10*x))-1) * (xdot**2)",
+                                             collision_geometry="-0.5 / (x ** 4) * (xdot ** 2)",
+                                             collision_finsler="0.01/(x**4) * xdot**2")
+        links = [] if kind == "grasp" else ["panda_link%d" % l for l in range(1, 9)]
+        static = kind == "static"
+        planner.set_components(collision_links=links, goal=create_dummy_goal_panda(), number_obstacles=4 if static else 0,
+                               number_dynamic_obstacles=0 if static else 4, dynamic_obstacle_dimension=3,
+                               number_plane_constraints=1, limits=config.PANDA_LIMITS)
+        planner.concretize(mode="vel", time_step=0.01)
+        kw = dict(q=g["q"][i], qdot=g["qd"][i], x_goal_0=g["g0"][i], weight_goal_0=2.0, angle_goal_1=R1,
+                  x_goal_1=[0.107, 0, 0], weight_goal_1=20.0, x_goal_2=[math.pi / 4], weight_goal_2=1.0,
+                  constraint_0=[0, 0, 1, -0.65],
+                  radius_body_panda_links={str(l): g["rb"][i][l - 3] for l in range(3, 9)},
+                  x_obsts=list(g["ox"][i]), radius_obsts=list(g["orad"][i]), x_obsts_dynamic=list(g["ox"][i]),
+                  xdot_obsts_dynamic=list(g["ov"][i]), xddot_obsts_dynamic=list(g["oa"][i]),
+                  radius_obsts_dynamic=list(g["orad"][i]))
+        action = planner.compute_action(**kw)
+        tol = 1e-7 if kind == "near" else 1e-9
+        assert np.abs(action - g["action"][i]).max() < tol * max(1.0, np.abs(g["action"][i]).max()), kind

@@ -1,0 +1,122 @@
+"""CPU, world_size 2 over gloo: the robot-sharded rollout driver (partitioning, padded all-gather, unpadding)
+with an oracle-backed stand-in for the two step kernels, against the oracle's fused rollout."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from multi_robot_fabrics_amd import config, scenarios, sharded
+
+
+class OracleStepBackend:
+    """Test-only stand-in for HipStepBackend: same two calls, computed by the float64 CPU oracle."""
+
+    def __init__(self, cfg):
+        import oracle_lib
+        self.o = oracle_lib
+        self.cfg = cfg
+        self.dtype, self.device = torch.float64, torch.device("cpu")
+        self.o.set_threads(1)
+
+    def _full(self, n_scen, first, count, rows_local):
+        """local [c, B*count] -> zero-padded global layout [c, B*N] (only the owned robots are filled)."""
+        N = self.cfg.n_robots
+        out = np.zeros((rows_local.shape[0], n_scen * N))
+        idx = np.array([s * N + first + l for s in range(n_scen) for l in range(count)])
+        out[:, idx] = rows_local
+        return out, idx
+
+    def predict(self, n_scen, first, count, q_io, qd, sph_own):
+        q_io += self.cfg.dt * qd
+        qf, idx = self._full(n_scen, first, count, q_io.numpy())
+        qdf, _ = self._full(n_scen, first, count, qd.numpy())
+        x, v, a = self.o.fk_spheres(self.cfg, qf, qdf)                       # [S,3,B*N]
+        S, N = self.cfg.n_spheres, self.cfg.n_robots
+        full = np.concatenate([x, v, a], axis=1).reshape(S, 9, n_scen, N)    # components x(3) v(3) a(3)
+        sph_own[:] = torch.from_numpy(full[:, :, :, first:first + count].transpose(3, 0, 1, 2).copy())
+
+    def action(self, n_scen, first, count, q, qd_io, prm, sph_all, sumsq):
+        S, N = self.cfg.n_spheres, self.cfg.n_robots
+        sa = sph_all.numpy()                                                  # [N,S,9,B]
+        rows = n_scen * count
+        M = S * (N - 1)
+        ox, ov, oa, orad = np.zeros((M, 3, rows)), np.zeros((M, 3, rows)), np.zeros((M, 3, rows)), np.zeros((M, rows))
+        for l in range(count):
+            m = 0
+            for j in range(N):
+                if j == first + l:
+                    continue
+                ox[m:m + S, :, l::count] = sa[j, :, 0:3, :]
+                if self.cfg.dynamic:
+                    ov[m:m + S, :, l::count] = sa[j, :, 3:6, :]
+                    oa[m:m + S, :, l::count] = sa[j, :, 6:9, :]
+                orad[m:m + S, l::count] = np.array(self.cfg.sphere_radius[:S])[:, None]
+                m += S
+        # the oracle picks the mount by row % n_robots: evaluate robot by robot with a single-robot config
+        act = np.zeros((7, rows))
+        for l in range(count):
+            c1 = self.cfg.copy()
+            c1.n_robots = 1
+            for k in range(12):
+                c1.mount[0][k] = self.cfg.mount[first + l][k]
+            sel = slice(l, rows, count)
+            _, act[:, sel] = self.o.compute_action(c1, q.numpy()[:, sel], qd_io.numpy()[:, sel], prm.numpy()[:, sel],
+                                                   ox[:, :, sel], ov[:, :, sel], oa[:, :, sel], orad[:, sel])
+        qd_io[:] = torch.from_numpy(act)
+        sumsq += torch.from_numpy((act ** 2).sum(0))
+
+
+def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+        batch = scenarios.panda_batch(cfg, n_scen, seed=77, x_min=0.08)
+        sr = sharded.ShardedRollout(cfg, rank, world, backend=OracleStepBackend(cfg))
+        rows = sr.own_rows(n_scen).numpy()
+        q = torch.from_numpy(np.ascontiguousarray(batch["q"][:, rows]))
+        qd = torch.from_numpy(np.ascontiguousarray(batch["qdot"][:, rows]))
+        prm = torch.from_numpy(np.ascontiguousarray(batch["params"][:, rows]))
+        avg = sr.rollout(q, qd, prm)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows, avg=avg.numpy(), q=q.numpy(), qd=qd.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n_robots", [2, 3])        # 3 robots on 2 ranks: uneven blocks (2 + 1), padded gather
+def test_sharded_rollout_world2_matches_fused(oracle, tmp_path, n_robots):
+    world, H, B = 2, 4, 5
+    mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path)), nprocs=world, join=True)
+    cfg = config.panda_config(n_robots=n_robots, horizon=H)
+    batch = scenarios.panda_batch(cfg, B, seed=77, x_min=0.08)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    seen = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        rows = d["rows"]
+        seen += list(rows)
+        assert np.abs(d["avg"] - want_avg[rows]).max() < 1e-12 * max(1.0, np.abs(want_avg).max())
+        assert np.abs(d["q"] - want_q[-1][:, rows]).max() < 1e-12
+        assert np.abs(d["qd"] - want_qd[-1][:, rows]).max() < 1e-11
+    assert sorted(seen) == list(range(B * n_robots))       # every (scenario, robot) row owned exactly once
+
+
+def test_single_rank_needs_no_process_group(oracle):
+    cfg = config.panda_config(n_robots=2, horizon=3)
+    batch = scenarios.panda_batch(cfg, 3, seed=5, x_min=0.08)
+    sr = sharded.ShardedRollout(cfg, 0, 1, backend=OracleStepBackend(cfg))
+    q, qd, prm = (torch.from_numpy(batch[k].copy()) for k in ("q", "qdot", "params"))
+    avg = sr.rollout(q, qd, prm)
+    want_avg, _, _ = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"])
+    assert np.abs(avg.numpy() - want_avg).max() < 1e-13
