@@ -78,7 +78,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenarios", type=int, default=65536, help="scenarios per GPU (batch B)")
+    ap.add_argument("--scenarios", type=int, default=0,
+                    help="scenarios per GPU (batch B); 0 = 6 full rounds of the chip's resident rollout waves")
     ap.add_argument("--robots", type=int, default=3)
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
@@ -101,6 +102,11 @@ def main():
     from multi_robot_fabrics_amd.runtime import FabricHandle
 
     N, H, B = args.robots, args.horizon, args.scenarios
+    if B <= 0:
+        # the rollout kernel runs one wave per SIMD (register-bound) with floor(64/N) scenarios per wave: size the
+        # batch to a whole number of rounds so that no SIMD idles in a ragged last round
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        B = 6 * cus * 4 * (64 // N)
     scalar = abi.F64 if args.dtype == "f64" else abi.F32
     sbytes = 8 if scalar == abi.F64 else 4
     # rollout planner: 8 link-origin spheres per robot (define_rollout_planners, EXJ:172-193); RF-CV: goals of the

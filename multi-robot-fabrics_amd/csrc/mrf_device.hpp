@@ -60,6 +60,60 @@ __device__ __forceinline__ float m_max(float a, float b) { return ::fmaxf(a, b);
 __device__ __forceinline__ void m_sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
 __device__ __forceinline__ void m_sincos(float x, float* s, float* c) { ::sincosf(x, s, c); }
 
+// Reciprocal and reciprocal square root without the IEEE scaling / fix-up sequences of `1/x` and sqrt():
+// hardware seed + Newton steps in fma form, ~1 ulp, for arguments well inside the normal range (all call sites:
+// distances, radii, metrics -- O(1e-6 .. 1e12)).  The parity tolerance is 1e-9; tests/test_gpu_parity.py
+// checks both against correctly rounded division.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  float e = __builtin_fmaf(-x, y, 1.0f);
+  return __builtin_fmaf(y, e, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(y, 0.5 * e, y);
+  e = __builtin_fma(-x * y, y, 1.0);
+  return __builtin_fma(y, 0.5 * e, y);
+}
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  float e = __builtin_fmaf(-x * y, y, 1.0f);
+  return __builtin_fmaf(y, 0.5f * e, y);
+}
+
+// sin/cos of a small angle |d| < 0.125 by Taylor series (truncation < 3e-18): used to advance cos q, sin q by
+// dq = dt*qdot inside a rollout instead of a full-range sincos per joint per step.
+template <typename T>
+__device__ __forceinline__ void small_sincos(T d, T& s, T& c) {
+  const T u = d * d;
+  T ps = T(-1.0 / 39916800.0);
+  ps = ps * u + T(1.0 / 362880.0);
+  ps = ps * u + T(-1.0 / 5040.0);
+  ps = ps * u + T(1.0 / 120.0);
+  ps = ps * u + T(-1.0 / 6.0);
+  ps = ps * u + T(1.0);
+  T pc = T(-1.0 / 3628800.0);
+  pc = pc * u + T(1.0 / 40320.0);
+  pc = pc * u + T(-1.0 / 720.0);
+  pc = pc * u + T(1.0 / 24.0);
+  pc = pc * u + T(-0.5);
+  pc = pc * u + T(1.0);
+  s = ps * d;
+  c = pc;
+}
+
+// keeps the compiler from merging a recomputation with an earlier, identical one (register lifetime control)
+__device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void opaque(float& x) { asm volatile("" : "+v"(x)); }
+
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
   c[0] = a[1] * b[2] - a[2] * b[1];
@@ -96,14 +150,14 @@ __device__ __forceinline__ T leaf_coeff(const LeafFn<T>& f, T x, T ix, T xd) {
   if (f.family == MRF_FAMILY_POW)
     v = f.k * powi(ix, f.p);
   else
-    v = f.k * (T(1) / (T(1) + f.c * m_exp(-f.s * x)) - T(1));
+    v = f.k * (fast_rcp(T(1) + f.c * m_exp(-f.s * x)) - T(1));
   return v * g;
 }
 
 // metric m = d2L/dxd2 and force f = m*h of a scalar barrier leaf at (x, xd)
 template <typename T>
 __device__ __forceinline__ void scalar_leaf(const LeafFn<T>& geo, const LeafFn<T>& fin, T x, T xd, T& m, T& f) {
-  T ix = T(1) / x;
+  T ix = fast_rcp(x);
   m = T(2) * leaf_coeff(fin, x, ix, xd);
   f = m * leaf_coeff(geo, x, ix, xd) * xd * xd;
 }
@@ -209,6 +263,8 @@ __device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T
   T w[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)}, vo[3] = {T(0), T(0), T(0)}, ao[3] = {T(0), T(0), T(0)};
   int s = 0;
   const int S = cfg.n_spheres;
+  int link_s = S > 0 ? cfg.sphere_link[0] : 0;
+  T off_s[3] = {cfg.sphere_off[0][0], cfg.sphere_off[0][1], cfg.sphere_off[0][2]};
 #pragma unroll 1
   for (int j = 0; j < 8; ++j) {
     T r[3];
@@ -255,20 +311,36 @@ __device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T
         w[k] += qdj * Z[k];
       }
     }
-    // spheres attached to panda_link(j+1): frame (X,Y,Z,o), angular state (w, al) of that link
-    while (s < S && cfg.sphere_link[s] == j + 1) {
-      T rr[3], x[3], v[3], a[3], wr[3], wwr[3], ar[3];
-      const T ox = cfg.sphere_off[s][0], oy = cfg.sphere_off[s][1], oz = cfg.sphere_off[s][2];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) rr[k] = ox * X[k] + oy * Y[k] + oz * Z[k];
-      cross3(w, rr, wr);
-      cross3(w, wr, wwr);
-      cross3(al, rr, ar);
+    // spheres attached to panda_link(j+1): frame (X,Y,Z,o), angular state (w, al) of that link.
+    // The table entry of the *next* sphere is fetched before the current one is consumed, so the scalar-load
+    // latency hides behind the leaf arithmetic instead of stalling the single resident wave.
+    while (s < S && link_s == j + 1) {
+      const T ox = off_s[0], oy = off_s[1], oz = off_s[2];
+      const int s_next = s + 1 < S ? s + 1 : s;
+      link_s = s + 1 < S ? cfg.sphere_link[s_next] : 0;
+      off_s[0] = cfg.sphere_off[s_next][0];
+      off_s[1] = cfg.sphere_off[s_next][1];
+      off_s[2] = cfg.sphere_off[s_next][2];
+      T x[3], v[3], a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        x[k] = o[k] + rr[k];
-        v[k] = vo[k] + wr[k];
-        a[k] = ao[k] + ar[k] + wwr[k];
+        x[k] = o[k];
+        v[k] = vo[k];
+        a[k] = ao[k];
+      }
+      if (!(ox == T(0) && oy == T(0) && oz == T(0))) {  // wave-uniform: the reference's rollout spheres are link origins
+        T rr[3], wr[3], wwr[3], ar[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rr[k] = ox * X[k] + oy * Y[k] + oz * Z[k];
+        cross3(w, rr, wr);
+        cross3(w, wr, wwr);
+        cross3(al, rr, ar);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          x[k] += rr[k];
+          v[k] += wr[k];
+          a[k] += ar[k] + wwr[k];
+        }
       }
       emit(s, x, v, a);
       ++s;
@@ -300,9 +372,50 @@ struct EgoPts {
   int nl[NP];   // number of links sharing the point (Panda: link5 and link6 share an origin)
 };
 
+// Collision-leaf policies.  LeafGeneric evaluates the two runtime families of mrf_leaf_fn.  LeafPow<PG,PL,GG,GL>
+// is the compile-time form of  h = kg/x^PG * gate * xd^2,  L = kl/x^PL * gate * xd^2  (the reference's Panda
+// strings are LeafPow<4,4,NONE,NONE>, EXJ:88-89) written so that no 1/R is needed: with t = 1/(d - R),
+//   1/x = R t,   m/R^2 = 2 kl R^(PL-2) t^PL,   f/R = (m/R^2) kg R^(PG-1) t^PG (n.v_rel)^2
+struct LeafGeneric {
+  static constexpr bool generic = true;
+};
+template <int PG, int PL, int GG, int GL>
+struct LeafPow {
+  static constexpr bool generic = false;
+  static constexpr int pg = PG, pl = PL, gg = GG, gl = GL;
+  static_assert(PL >= 2 && PG >= 1, "LeafPow needs PL >= 2 and PG >= 1");
+};
+
+template <int P, typename T>
+__device__ __forceinline__ T cpow(T x) {  // x^P, P compile-time
+  if constexpr (P == 0) return T(1);
+  else if constexpr (P == 1) return x;
+  else if constexpr (P % 2 == 0) { T h = cpow<P / 2>(x); return h * h; }
+  else return x * cpow<P - 1>(x);
+}
+
+// weights of one spherical-obstacle leaf:  wm = m/R^2,  wf = f/R   (d = distance, nv = n.v_rel, R = r_o + r_b)
+template <class CL, typename T>
+__device__ __forceinline__ void collision_weights(const DevCfg<T>& cfg, T d, T nv, T R, T& wm, T& fR) {
+  if constexpr (CL::generic) {
+    T iR = fast_rcp(R);
+    T x = d * iR - T(1);
+    T xd = nv * iR;
+    T m, f;
+    scalar_leaf(cfg.cg, cfg.cf, x, xd, m, f);
+    wm = m * iR * iR;
+    fR = f * iR;
+  } else {
+    T t = fast_rcp(d - R);
+    T gl = gate_value<T>(CL::gl, nv), gg = gate_value<T>(CL::gg, nv);  // sign(xd) == sign(nv), R > 0
+    wm = T(2) * cfg.cf.k * gl * cpow<CL::pl - 2>(R) * cpow<CL::pl>(t);
+    fR = wm * (cfg.cg.k * gg) * cpow<CL::pg - 1>(R) * cpow<CL::pg>(t) * nv * nv;
+  }
+}
+
 // Add the spherical-obstacle leaves of all ego points against one obstacle sphere.
 // a_o is the obstacle's reference acceleration as the reference passes it (already sign-carrying).
-template <typename T, int NP>
+template <class CL, typename T, int NP>
 __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* xo,
                                                     const T* vo, const T* a_o, T ro, bool planar, EgoAcc<T, NP>& acc) {
 #pragma unroll
@@ -310,8 +423,8 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
     T dx[3] = {E.p[g][0] - xo[0], E.p[g][1] - xo[1], planar ? T(0) : E.p[g][2] - xo[2]};
     T vr[3] = {E.v[g][0] - vo[0], E.v[g][1] - vo[1], planar ? T(0) : E.v[g][2] - vo[2]};
     T d2 = dot3(dx, dx);
-    T d = m_sqrt(d2);
-    T id = T(1) / d;
+    T id = fast_rsqrt(d2);
+    T d = d2 * id;
     T n[3] = {dx[0] * id, dx[1] * id, dx[2] * id};
     T nv = dot3(n, vr);
     T kap = (dot3(vr, vr) - nv * nv) * id;
@@ -321,22 +434,19 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       if (l < E.nl[g]) {
-        T iR = T(1) / (ro + E.rb[g][l]);
-        T x = d * iR - T(1);
-        T xd = nv * iR;
-        T m, f;
-        scalar_leaf(cfg.cg, cfg.cf, x, xd, m, f);
-        T wm = m * iR * iR;
+        T wm, fR;
+        collision_weights<CL>(cfg, d, nv, ro + E.rb[g][l], wm, fR);
         wM += wm;
-        wf += f * iR + wm * curv;
+        wf += fR + wm * curv;
       }
     }
-    acc.A[g][0] += wM * n[0] * n[0];
-    acc.A[g][1] += wM * n[0] * n[1];
-    acc.A[g][2] += wM * n[0] * n[2];
-    acc.A[g][3] += wM * n[1] * n[1];
-    acc.A[g][4] += wM * n[1] * n[2];
-    acc.A[g][5] += wM * n[2] * n[2];
+    T w0 = wM * n[0], w1 = wM * n[1], w2 = wM * n[2];
+    acc.A[g][0] += w0 * n[0];
+    acc.A[g][1] += w0 * n[1];
+    acc.A[g][2] += w0 * n[2];
+    acc.A[g][3] += w1 * n[1];
+    acc.A[g][4] += w1 * n[2];
+    acc.A[g][5] += w2 * n[2];
     acc.b[g][0] += wf * n[0];
     acc.b[g][1] += wf * n[1];
     acc.b[g][2] += wf * n[2];
@@ -347,7 +457,7 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
 template <typename T, int NP>
 __device__ __forceinline__ void accumulate_plane(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* con,
                                                  EgoAcc<T, NP>& acc) {
-  T ina = T(1) / m_sqrt(con[0] * con[0] + con[1] * con[1] + con[2] * con[2]);
+  T ina = fast_rsqrt(con[0] * con[0] + con[1] * con[1] + con[2] * con[2]);
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
     T val = (con[0] * E.p[g][0] + con[1] * E.p[g][1] + con[2] * E.p[g][2] + con[3]) * ina;
@@ -366,12 +476,13 @@ __device__ __forceinline__ void accumulate_plane(const DevCfg<T>& cfg, const Ego
         wf += f;
       }
     }
-    acc.A[g][0] += wM * n[0] * n[0];
-    acc.A[g][1] += wM * n[0] * n[1];
-    acc.A[g][2] += wM * n[0] * n[2];
-    acc.A[g][3] += wM * n[1] * n[1];
-    acc.A[g][4] += wM * n[1] * n[2];
-    acc.A[g][5] += wM * n[2] * n[2];
+    T w0 = wM * n[0], w1 = wM * n[1], w2 = wM * n[2];
+    acc.A[g][0] += w0 * n[0];
+    acc.A[g][1] += w0 * n[1];
+    acc.A[g][2] += w0 * n[2];
+    acc.A[g][3] += w1 * n[1];
+    acc.A[g][4] += w1 * n[2];
+    acc.A[g][5] += w2 * n[2];
     acc.b[g][0] += wf * n[0];
     acc.b[g][1] += wf * n[1];
     acc.b[g][2] += wf * n[2];
@@ -428,7 +539,7 @@ __device__ __forceinline__ void ldl_solve(const QSpec<T, N>& S, T eps, T (&h)[N]
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[tri<N>(k, j)] * L[tri<N>(k, j)] * L[tri<N>(k, k)];
     L[tri<N>(j, j)] = d;       // d_j
-    dinv[j] = T(1) / d;
+    dinv[j] = fast_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       T v = L[tri<N>(j, i)];
@@ -465,7 +576,7 @@ __device__ __forceinline__ void attractor(const DevCfg<T>& cfg, const T* x, T w,
   T ar = cfg.attr_a * r;
   twoA = T(2) * ((cfg.attr_mu - cfg.attr_ml) * m_exp(-ar * ar) + cfg.attr_ml);
   // grad psi = w k tanh(alpha r) x/r ; 0 at r == 0 (build convention, DESIGN.md "deviations")
-  T g = r > T(0) ? w * cfg.attr_k * m_tanh(cfg.attr_alpha * r) / r : T(0);
+  T g = r > T(0) ? w * cfg.attr_k * m_tanh(cfg.attr_alpha * r) * fast_rcp(r) : T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) f[k] = twoA * g * x[k];
 }
@@ -484,7 +595,7 @@ __device__ __forceinline__ void finish(const DevCfg<T>& cfg, const T (&qd)[N], b
     T qh = T(0);
 #pragma unroll
     for (int j = 0; j < N; ++j) qh += qd[j] * hf[j];
-    T alpha_f = -qh / (cfg.eps + qq);
+    T alpha_f = -qh * fast_rcp(cfg.eps + qq);
     T eta = T(0.5) * (m_tanh(-cfg.eta_a * qq - cfg.eta_s) + T(1));
     T a_ex = eta * alpha_g + (T(1) - eta) * alpha_f;
     T beta = T(0.5) * (m_tanh(-cfg.beta_a * (xpsi - cfg.beta_r)) + T(1)) * cfg.beta_b + cfg.beta_s +
@@ -505,15 +616,27 @@ __device__ __forceinline__ void finish(const DevCfg<T>& cfg, const T (&qd)[N], b
 }
 
 // ------------------------------------------------------------------------------------ Panda row solve
+// Per-row parameters are read where they are used (coalesced, L2-resident) instead of being held in 29 registers
+// across the obstacle loop; the rollout overrides x_goal_0 with its estimate (RF-CV).
 template <typename T>
-struct PandaRow {
-  T q[7], qd[7], cq[7], sq[7];
-  T prm[MRF_NPARAM];
+struct PrmView {
+  const T* __restrict__ base;
+  int64_t rows, r;
+  T g0[3];
+  bool own_goal;  // x_goal_0 comes from g0 instead of memory
+  __device__ __forceinline__ T operator[](int i) const {
+    if (i < 3 && own_goal) return g0[i];
+    return base[i * rows + r];
+  }
 };
 
 template <typename T>
-__device__ __forceinline__ void panda_ego_points(const DevCfg<T>& cfg, const PandaKin<T>& K, const T* prm,
-                                                 EgoPts<T, NG>& E) {
+struct PandaState {
+  T q[7], qd[7], cq[7], sq[7];
+};
+
+template <typename T, class PRM>
+__device__ __forceinline__ void panda_ego_points(const PandaKin<T>& K, const PRM& prm, EgoPts<T, NG>& E) {
   constexpr int jo[4] = {2, 3, 4, 6};  // joint-origin index of links 3, 4, 5(=6), 7
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -527,25 +650,28 @@ __device__ __forceinline__ void panda_ego_points(const DevCfg<T>& cfg, const Pan
     E.p[4][k] = K.p8[k];
     E.v[4][k] = K.v8[k];
   }
-  const T* rb = prm + MRF_P_RADIUS_BODY;  // links 3..8
-  E.rb[0][0] = rb[0]; E.rb[0][1] = T(0); E.nl[0] = 1;
-  E.rb[1][0] = rb[1]; E.rb[1][1] = T(0); E.nl[1] = 1;
-  E.rb[2][0] = rb[2]; E.rb[2][1] = rb[3]; E.nl[2] = 2;
-  E.rb[3][0] = rb[4]; E.rb[3][1] = T(0); E.nl[3] = 1;
-  E.rb[4][0] = rb[5]; E.rb[4][1] = T(0); E.nl[4] = 1;
-  (void)cfg;
+  // body radii of links 3..8
+  E.rb[0][0] = prm[MRF_P_RADIUS_BODY + 0]; E.rb[0][1] = T(0); E.nl[0] = 1;
+  E.rb[1][0] = prm[MRF_P_RADIUS_BODY + 1]; E.rb[1][1] = T(0); E.nl[1] = 1;
+  E.rb[2][0] = prm[MRF_P_RADIUS_BODY + 2]; E.rb[2][1] = prm[MRF_P_RADIUS_BODY + 3]; E.nl[2] = 2;
+  E.rb[3][0] = prm[MRF_P_RADIUS_BODY + 4]; E.rb[3][1] = T(0); E.nl[3] = 1;
+  E.rb[4][0] = prm[MRF_P_RADIUS_BODY + 5]; E.rb[4][1] = T(0); E.nl[4] = 1;
 }
 
 // Everything after the obstacle loop: plane + pullbacks + limits + attractors + solves + damping.
-template <typename T>
-__device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const PandaRow<T>& R, const PandaKin<T>& K,
-                                                 const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc, T (&qdd)[7], T (&act)[7]) {
+template <typename T, class PRM>
+__device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const PandaState<T>& R, const PRM& prm,
+                                                 const PandaKin<T>& K, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc,
+                                                 T (&qdd)[7], T (&act)[7]) {
   QSpec<T, 7> S;
   S.zero();
 #pragma unroll
   for (int j = 0; j < 7; ++j) S.M[tri<7>(j, j)] = cfg.base_mass;
   if (cfg.n_ego > 0) {
-    if (cfg.n_planes > 0) accumulate_plane(cfg, E, R.prm + MRF_P_CONSTRAINT_0, acc);
+    if (cfg.n_planes > 0) {
+      T con[4] = {prm[MRF_P_CONSTRAINT_0], prm[MRF_P_CONSTRAINT_0 + 1], prm[MRF_P_CONSTRAINT_0 + 2], prm[MRF_P_CONSTRAINT_0 + 3]};
+      accumulate_plane(cfg, E, con, acc);
+    }
     constexpr int jo[4] = {2, 3, 4, 6};
     // t = b + A c with c = jsign * Jdot qd of the point
 #define MRF_PULL(g, NC, pp, aa)                                                                \
@@ -583,32 +709,34 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
     qq += R.qd[j] * R.qd[j];
     qh += R.qd[j] * hg[j];
   }
-  T alpha_g = -qh / (cfg.eps + qq);
+  T alpha_g = -qh * fast_rcp(cfg.eps + qq);
   T xpsi = T(0);
   const bool forced = cfg.n_goals > 0;
   if (forced) {
     // attractor 0: panda_hand position -> x_goal_0   (EXJ:32-41)
     {
-      T x0[3] = {K.p8[0] - R.prm[MRF_P_X_GOAL_0], K.p8[1] - R.prm[MRF_P_X_GOAL_0 + 1], K.p8[2] - R.prm[MRF_P_X_GOAL_0 + 2]};
+      T x0[3] = {K.p8[0] - prm[MRF_P_X_GOAL_0], K.p8[1] - prm[MRF_P_X_GOAL_0 + 1], K.p8[2] - prm[MRF_P_X_GOAL_0 + 2]};
       T twoA, f0[3];
-      attractor<T, 3>(cfg, x0, R.prm[MRF_P_WEIGHT_GOAL_0], twoA, f0, xpsi);
+      attractor<T, 3>(cfg, x0, prm[MRF_P_WEIGHT_GOAL_0], twoA, f0, xpsi);
       T A6[6] = {twoA, T(0), T(0), twoA, T(0), twoA};
       T t[3] = {f0[0] + twoA * cfg.jsign * K.a8[0], f0[1] + twoA * cfg.jsign * K.a8[1], f0[2] + twoA * cfg.jsign * K.a8[2]};
       pull_point<T, 6>(S, K, K.p8, A6, t);
     }
     if (cfg.n_goals > 1) {
       // attractor 1: R (p_hand - p_link7) -> x_goal_1 ; p_hand - p_link7 = 0.107 z_6   (EXJ:42-52)
-      const T* Rm = R.prm + MRF_P_ANGLE_GOAL_1;
+      T Rm[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rm[i] = prm[MRF_P_ANGLE_GOAL_1 + i];
       T d8[3] = {K.p8[0] - K.o[6][0], K.p8[1] - K.o[6][1], K.p8[2] - K.o[6][2]};
       T da[3] = {K.a8[0] - K.ao[6][0], K.a8[1] - K.ao[6][1], K.a8[2] - K.ao[6][2]};
       T x1[3], c1[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        x1[i] = Rm[3 * i] * d8[0] + Rm[3 * i + 1] * d8[1] + Rm[3 * i + 2] * d8[2] - R.prm[MRF_P_X_GOAL_1 + i];
+        x1[i] = Rm[3 * i] * d8[0] + Rm[3 * i + 1] * d8[1] + Rm[3 * i + 2] * d8[2] - prm[MRF_P_X_GOAL_1 + i];
         c1[i] = cfg.jsign * (Rm[3 * i] * da[0] + Rm[3 * i + 1] * da[1] + Rm[3 * i + 2] * da[2]);
       }
       T twoA, f1[3], rn;
-      attractor<T, 3>(cfg, x1, R.prm[MRF_P_WEIGHT_GOAL_1], twoA, f1, rn);
+      attractor<T, 3>(cfg, x1, prm[MRF_P_WEIGHT_GOAL_1], twoA, f1, rn);
       T t[3] = {f1[0] + twoA * c1[0], f1[1] + twoA * c1[1], f1[2] + twoA * c1[2]};
       T J[6][3];
 #pragma unroll
@@ -626,9 +754,9 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
     }
     if (cfg.n_goals > 2) {
       // attractor 2: joint index 6 -> x_goal_2   (EXJ:53-60)
-      T x2[1] = {R.q[6] - R.prm[MRF_P_X_GOAL_2]};
+      T x2[1] = {R.q[6] - prm[MRF_P_X_GOAL_2]};
       T twoA, f2[1], rn;
-      attractor<T, 1>(cfg, x2, R.prm[MRF_P_WEIGHT_GOAL_2], twoA, f2, rn);
+      attractor<T, 1>(cfg, x2, prm[MRF_P_WEIGHT_GOAL_2], twoA, f2, rn);
       S.M[tri<7>(6, 6)] += twoA;
       S.f[6] += f2[0];
     }
@@ -638,6 +766,33 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
     for (int j = 0; j < 7; ++j) hf[j] = hg[j];
   }
   finish<T, 7>(cfg, R.qd, forced, alpha_g, hg, hf, xpsi, qdd, act);
+}
+
+// One fabric solve of a Panda row.  `obstacles(E, acc)` adds the spherical-obstacle leaves.  The own chain is
+// walked twice: once for the ego points the obstacle loop needs (positions, velocities), once afterwards for the
+// joint axes / origins / curvature terms of the pullback -- recomputing ~300 flops is cheaper than keeping
+// ~60 more values live across the loop (register pressure is what limits these kernels).
+template <typename T, class PRM, class Obst>
+__device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* __restrict__ mount, const PandaState<T>& R,
+                                                const PRM& prm, Obst obstacles, T (&qdd)[7], T (&act)[7]) {
+  EgoPts<T, NG> E;
+  {
+    PandaKin<T> K1;
+    panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K1);
+    panda_ego_points(K1, prm, E);
+  }
+  EgoAcc<T, NG> acc;
+  acc.zero();
+  if (cfg.n_ego > 0) obstacles(E, acc);
+  PandaState<T> R2 = R;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    opaque(R2.cq[j]);
+    opaque(R2.sq[j]);
+  }
+  PandaKin<T> K;
+  panda_walk_own<T>(mount, R2.cq, R2.sq, R2.qd, K);
+  panda_finish_row(cfg, R, prm, K, E, acc, qdd, act);
 }
 
 // ------------------------------------------------------------------------------------ planar point robot
@@ -678,7 +833,7 @@ __device__ __forceinline__ void planar_finish_row(const DevCfg<T>& cfg, const Pl
     qq += R.qd[j] * R.qd[j];
     qh += R.qd[j] * hg[j];
   }
-  T alpha_g = -qh / (cfg.eps + qq);
+  T alpha_g = -qh * fast_rcp(cfg.eps + qq);
   T xpsi = T(0);
   const bool forced = cfg.n_goals > 0;
   if (forced) {

@@ -20,27 +20,42 @@
 
 namespace mrf {
 
-// ---------------------------------------------------------------------------- row loads
+// ---------------------------------------------------------------------------- row state
 template <typename T>
-__device__ __forceinline__ void load_panda_row(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
-                                               const T* __restrict__ prm, PandaRow<T>& R) {
+__device__ __forceinline__ void load_state(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
+                                           PandaState<T>& R) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     R.q[j] = q[j * rows + r];
     R.qd[j] = qd[j * rows + r];
+    m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
   }
-#pragma unroll
-  for (int p = 0; p < MRF_NPARAM; ++p) R.prm[p] = prm[p * rows + r];
 }
 
-template <typename T>
-__device__ __forceinline__ void panda_trig(PandaRow<T>& R) {
+// obstacle loop over HBM arrays [n_obst][3][rows] (compute_action / Cartesian rollout); tk = elapsed obstacle time
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int64_t rows, int64_t r, int n_obst,
+                                                      int n_static, const T* __restrict__ ox, const T* __restrict__ ov,
+                                                      const T* __restrict__ oa, const T* __restrict__ orad, T tk,
+                                                      bool allow_planar, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#pragma unroll 1
+  for (int m = 0; m < n_obst; ++m) {
+    const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
+    T xo[3], vo[3], ao[3];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    for (int c = 0; c < 3; ++c) {
+      const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
+      vo[c] = (ov && !is_static) ? ov[idx] : T(0);
+      xo[c] = ox[idx] + tk * vo[c];  // Cartesian rollout: x += dt*v per step (FPC:448-453); tk = 0 otherwise
+      ao[c] = (oa && !is_static) ? oa[idx] : T(0);
+    }
+    accumulate_obstacle<CL>(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r],
+                            allow_planar && !is_static && cfg.obst_dim == 2, acc);
+  }
 }
 
 // ---------------------------------------------------------------------------- compute_action
-template <typename T>
+template <typename T, class CL>
 __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                        const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ prm, int n_obst, int n_static,
@@ -50,32 +65,16 @@ __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restric
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const DevCfg<T>& cfg = *cfgp;
-  PandaRow<T> R;
-  load_panda_row(rows, r, q, qd, prm, R);
-  panda_trig(R);
-  PandaKin<T> K;
-  panda_walk_own<T>(cfg.mount[(int)(r % cfg.n_robots)], R.cq, R.sq, R.qd, K);
-  EgoPts<T, NG> E;
-  panda_ego_points(cfg, K, R.prm, E);
-  EgoAcc<T, NG> acc;
-  acc.zero();
-  if (cfg.n_ego > 0) {
-#pragma unroll 1
-    for (int m = 0; m < n_obst; ++m) {
-      const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
-      T xo[3], vo[3], ao[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
-        xo[c] = ox[idx];
-        vo[c] = (ov && !is_static) ? ov[idx] : T(0);
-        ao[c] = (oa && !is_static) ? oa[idx] : T(0);
-      }
-      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], !is_static && cfg.obst_dim == 2, acc);
-    }
-  }
+  PandaState<T> R;
+  load_state(rows, r, q, qd, R);
+  PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   T qdd[7], act[7];
-  panda_finish_row(cfg, R, K, E, acc, qdd, act);
+  panda_solve_row(
+      cfg, cfg.mount[(int)(r % cfg.n_robots)], R, P,
+      [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+        obstacles_from_arrays<CL>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E, acc);
+      },
+      qdd, act);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     if (qdd_out) qdd_out[j * rows + r] = qdd[j];
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
   if (cfg.n_ego > 0) {
 #pragma unroll 1
     for (int m = 0; m < n_obst; ++m) {
-      const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
+      const bool is_static = m < n_static;
       T xo[3], vo[3], ao[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -117,7 +116,8 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
         vo[c] = (ov && !is_static) ? ov[idx] : T(0);
         ao[c] = (oa && !is_static) ? oa[idx] : T(0);
       }
-      accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], !is_static && cfg.obst_dim == 2, acc);
+      accumulate_obstacle<LeafGeneric>(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r],
+                                       !is_static && cfg.obst_dim == 2, acc);
     }
   }
   T qdd[3], act[3];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 // exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
 // stays inside the wave: each lane publishes cos q, sin q, qdot of its 7 joints to a 21 x 64 LDS tile and
 // re-walks the other robots' chains from that tile, streaming their spheres straight into its leaf sums.
-template <typename T>
+template <typename T, class CL>
 __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
@@ -154,26 +154,48 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
   const int64_t rows = n_scen * N;
   const int64_t row = scen * N + li;
 
-  PandaRow<T> R;
-  load_panda_row(rows, row, q0, qd0, prm, R);
+  PandaState<T> R;
+  load_state(rows, row, q0, qd0, R);
   const T* mount_own = cfg.mount[li];
+  PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
 
   if ((cfg.goal_mask >> li) & 1) {
     // RF-CV: the goal of this robot is not communicated; use x_ee + T * v_ee (EXC:355-357)
-    panda_trig(R);
     PandaKin<T> K0;
     panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K0);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) R.prm[MRF_P_X_GOAL_0 + c] = K0.p8[c] + cfg.goal_T * K0.v8[c];
+    for (int c = 0; c < 3; ++c) P.g0[c] = K0.p8[c] + cfg.goal_T * K0.v8[c];
+    P.own_goal = true;
   }
 
   T sumsq = T(0);
   const int H = cfg.horizon;
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
+    // system_step 'vel' (FPJ:77-80): q += dt*qdot.  cos q / sin q advance by the angle-sum formula while every
+    // |dq| in the wave is small; a full sincos otherwise.
+    T dq[7];
+    bool small = true;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) R.q[j] += cfg.dt * R.qd[j];  // system_step 'vel' (FPJ:77-80)
-    panda_trig(R);
+    for (int j = 0; j < 7; ++j) {
+      dq[j] = cfg.dt * R.qd[j];
+      small = small && (m_abs(dq[j]) < T(0.125));
+      R.q[j] += dq[j];
+    }
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T sd, cd;
+        small_sincos(dq[j], sd, cd);
+        const T c = R.cq[j] * cd - R.sq[j] * sd;
+        const T s = R.sq[j] * cd + R.cq[j] * sd;
+        R.cq[j] = c;
+        R.sq[j] = s;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -182,39 +204,34 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
       xch[(3 * j + 2) * 64 + lane] = R.qd[j];
     }
     __syncthreads();
-    PandaKin<T> K;
-    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
-    EgoPts<T, NG> E;
-    panda_ego_points(cfg, K, R.prm, E);
-    EgoAcc<T, NG> acc;
-    acc.zero();
-    if (cfg.n_ego > 0) {
-#pragma unroll 1
-      for (int d = 1; d < N; ++d) {
-        int jr = li + d;
-        if (jr >= N) jr -= N;
-        const int src = ls * N + jr;
-        const T* mount_o = cfg.mount[jr];
-        panda_walk_spheres<T>(
-            cfg, mount_o,
-            [&](int j, T& c, T& s, T& qdj) {
-              c = xch[(3 * j + 0) * 64 + src];
-              s = xch[(3 * j + 1) * 64 + src];
-              qdj = xch[(3 * j + 2) * 64 + src];
-            },
-            [&](int s, const T* x, const T* v, const T* a) {
-              T vv[3], aa[3];
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                vv[c] = cfg.dynamic ? v[c] : T(0);               // FPJ:215-220
-                aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);   // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
-              }
-              accumulate_obstacle(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
-            });
-      }
-    }
     T qdd[7], act[7];
-    panda_finish_row(cfg, R, K, E, acc, qdd, act);
+    panda_solve_row(
+        cfg, mount_own, R, P,
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#pragma unroll 1
+          for (int d = 1; d < N; ++d) {
+            int jr = li + d;
+            if (jr >= N) jr -= N;
+            const int src = ls * N + jr;
+            panda_walk_spheres<T>(
+                cfg, cfg.mount[jr],
+                [&](int j, T& c, T& s, T& qdj) {
+                  c = xch[(3 * j + 0) * 64 + src];
+                  s = xch[(3 * j + 1) * 64 + src];
+                  qdj = xch[(3 * j + 2) * 64 + src];
+                },
+                [&](int s, const T* x, const T* v, const T* a) {
+                  T vv[3], aa[3];
+#pragma unroll
+                  for (int c = 0; c < 3; ++c) {
+                    vv[c] = cfg.dynamic ? v[c] : T(0);              // FPJ:215-220
+                    aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);  // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
+                  }
+                  accumulate_obstacle<CL>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
+                });
+          }
+        },
+        qdd, act);
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       R.qd[j] = act[j];  // FPJ:233
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
 }
 
 // ---------------------------------------------------------------------------- Cartesian rollout
-template <typename T>
+template <typename T, class CL>
 __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
                                                              const T* __restrict__ prm, int n_obst, int n_static,
@@ -244,38 +261,22 @@ __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __r
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
   const DevCfg<T>& cfg = *cfgp;
-  PandaRow<T> R;
-  load_panda_row(rows, r, q0, qd0, prm, R);
+  PandaState<T> R;
+  load_state(rows, r, q0, qd0, R);
+  PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   const T* mount_own = cfg.mount[(int)(r % cfg.n_robots)];
   T sumsq = T(0);
   T tk = T(0);  // elapsed obstacle time k*dt
   const int H = cfg.horizon;
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
-    panda_trig(R);
-    PandaKin<T> K;
-    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
-    EgoPts<T, NG> E;
-    panda_ego_points(cfg, K, R.prm, E);
-    EgoAcc<T, NG> acc;
-    acc.zero();
-    if (cfg.n_ego > 0) {
-#pragma unroll 1
-      for (int m = 0; m < n_obst; ++m) {
-        const bool is_static = m < n_static;
-        T xo[3], vo[3], ao[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
-          vo[c] = is_static ? T(0) : ov[idx];
-          xo[c] = ox0[idx] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
-          ao[c] = (oa && !is_static) ? oa[idx] : T(0);
-        }
-        accumulate_obstacle(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r], false, acc);
-      }
-    }
     T qdd[7], act[7];
-    panda_finish_row(cfg, R, K, E, acc, qdd, act);
+    panda_solve_row(
+        cfg, mount_own, R, P,
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+          obstacles_from_arrays<CL>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc);
+        },
+        qdd, act);
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       if (cfg.mode == MRF_MODE_VEL) {
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __r
         R.qd[j] += cfg.dt * act[j];
       }
       sumsq += R.qd[j] * R.qd[j];
+      m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
     }
     if (traj_q) {
 #pragma unroll
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
 }
 
 // action: fabric solve of the owned robots against every other robot's published spheres.
-template <typename T>
+template <typename T, class CL>
 __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
                                                       int robot_count, const T* __restrict__ q, T* __restrict__ qd_io,
                                                       const T* __restrict__ prm, const T* __restrict__ sph_all,
@@ -400,37 +402,33 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
   const int64_t scen = r / robot_count;
   const int lr = (int)(r - scen * robot_count);
   const int me = robot_first + lr;
-  PandaRow<T> R;
-  load_panda_row(rows, r, q, qd_io, prm, R);
-  panda_trig(R);
-  PandaKin<T> K;
-  panda_walk_own<T>(cfg.mount[me], R.cq, R.sq, R.qd, K);
-  EgoPts<T, NG> E;
-  panda_ego_points(cfg, K, R.prm, E);
-  EgoAcc<T, NG> acc;
-  acc.zero();
+  PandaState<T> R;
+  load_state(rows, r, q, (const T*)qd_io, R);
+  PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   const int N = cfg.n_robots, S = cfg.n_spheres;
-  if (cfg.n_ego > 0) {
-#pragma unroll 1
-    for (int d = 1; d < N; ++d) {
-      int jr = me + d;
-      if (jr >= N) jr -= N;
-#pragma unroll 1
-      for (int s = 0; s < S; ++s) {
-        const int64_t base = ((int64_t)(jr * S + s) * 9) * n_scen + scen;
-        T x[3], v[3], a[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          x[c] = sph_all[base + (int64_t)c * n_scen];
-          v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
-          a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
-        }
-        accumulate_obstacle(cfg, E, x, v, a, cfg.sphere_r[s], false, acc);
-      }
-    }
-  }
   T qdd[7], act[7];
-  panda_finish_row(cfg, R, K, E, acc, qdd, act);
+  panda_solve_row(
+      cfg, cfg.mount[me], R, P,
+      [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#pragma unroll 1
+        for (int d = 1; d < N; ++d) {
+          int jr = me + d;
+          if (jr >= N) jr -= N;
+#pragma unroll 1
+          for (int s = 0; s < S; ++s) {
+            const int64_t base = ((int64_t)(jr * S + s) * 9) * n_scen + scen;
+            T x[3], v[3], a[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              x[c] = sph_all[base + (int64_t)c * n_scen];
+              v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
+              a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
+            }
+            accumulate_obstacle<CL>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc);
+          }
+        }
+      },
+      qdd, act);
   T ss = T(0);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
@@ -564,6 +562,25 @@ int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args.
   return check_hip(h, hipGetLastError(), "kernel launch");
 }
 
+// the reference's Panda collision strings (EXJ:88-89) get the compile-time leaf policy, anything else the generic one
+using LeafPanda = mrf::LeafPow<4, 4, MRF_GATE_NONE, MRF_GATE_NONE>;
+bool is_panda_leaf(const mrf_config& c) {
+  const mrf_leaf_fn &g = c.collision_geometry, &f = c.collision_finsler;
+  return g.family == MRF_FAMILY_POW && f.family == MRF_FAMILY_POW && g.p == 4 && f.p == 4 &&
+         g.gate == MRF_GATE_NONE && f.gate == MRF_GATE_NONE;
+}
+
+template <typename F>
+int dispatch_scalar(mrf_handle* h, F f) {
+  return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
+}
+template <typename F>
+int dispatch(mrf_handle* h, F f) {
+  const bool fast = is_panda_leaf(h->cfg);
+  if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafPanda{}) : f(double{}, mrf::LeafGeneric{});
+  return fast ? f(float{}, LeafPanda{}) : f(float{}, mrf::LeafGeneric{});
+}
+
 }  // namespace
 
 extern "C" {
@@ -679,29 +696,29 @@ const char* mrf_last_error(const mrf_handle* h) { return h ? h->err.c_str() : "n
   if (!(h)->dcfg) return fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)");
 
 int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
-                       int32_t n_obst, int32_t n_obst_static, const void* ox, const void* ov, const void* oa, const void* orad,
-                       void* qddot_out, void* action_out, void* stream) {
+                       int32_t n_obst, int32_t n_obst_static, const void* ox, const void* ov, const void* oa,
+                       const void* orad, void* qddot_out, void* action_out, void* stream) {
   MRF_CHECK_READY(h);
   if (rows == 0) return MRF_OK;  // empty batch: nothing to read or write, pointers may be NULL
   if (rows < 0 || n_obst < 0 || n_obst_static < 0 || n_obst_static > n_obst || !q || !qdot || !params || !action_out)
     return fail(h, MRF_E_ARG, "null/negative argument");
   if (n_obst > 0 && (!ox || !orad)) return fail(h, MRF_E_ARG, "obstacle arrays missing");
-  if (rows == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
-  const bool panda = h->cfg.model == MRF_MODEL_PANDA7;
-  if (h->cfg.scalar == MRF_F64) {
-    using T = double;
-    auto k = panda ? mrf::k_action_panda<T> : mrf::k_action_planar<T>;
-    return launch(h, k, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
-                  (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
-                  (const T*)orad, (T*)qddot_out, (T*)action_out);
-  }
-  using T = float;
-  auto k = panda ? mrf::k_action_panda<T> : mrf::k_action_planar<T>;
-  return launch(h, k, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
-                (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
-                (const T*)orad, (T*)qddot_out, (T*)action_out);
+  if (h->cfg.model == MRF_MODEL_PLANAR3)
+    return dispatch_scalar(h, [&](auto t) {
+      using T = decltype(t);
+      return launch(h, mrf::k_action_planar<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
+                    (const T*)qdot, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov,
+                    (const T*)oa, (const T*)orad, (T*)qddot_out, (T*)action_out);
+    });
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using CL = decltype(cl);
+    return launch(h, mrf::k_action_panda<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
+                  (const T*)qdot, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov,
+                  (const T*)oa, (const T*)orad, (T*)qddot_out, (T*)action_out);
+  });
 }
 
 int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
@@ -716,38 +733,32 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   hipStream_t st = (hipStream_t)stream;
   const int spw = 64 / h->cfg.n_robots;
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
-  if (h->cfg.scalar == MRF_F64) {
-    using T = double;
-    return launch(h, mrf::k_rollout_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0,
-                  (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
-  }
-  using T = float;
-  return launch(h, mrf::k_rollout_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0,
-                (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using CL = decltype(cl);
+    return launch(h, mrf::k_rollout_panda<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+                  (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  });
 }
 
 int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,
-                          int32_t n_obst, int32_t n_obst_static, const void* ox0, const void* ov, const void* oa, const void* orad,
-                          void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+                          int32_t n_obst, int32_t n_obst_static, const void* ox0, const void* ov, const void* oa,
+                          const void* orad, void* avg_out, void* traj_q, void* traj_qd, void* stream) {
   MRF_CHECK_READY(h);
   if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "rollouts are defined for the panda7 model only");
   if (rows == 0) return MRF_OK;
   if (rows < 0 || n_obst < 0 || n_obst_static < 0 || n_obst_static > n_obst || !q0 || !qdot0 || !params || !avg_out)
     return fail(h, MRF_E_ARG, "null/negative argument");
   if (n_obst > 0 && (!ox0 || !orad || (n_obst > n_obst_static && !ov))) return fail(h, MRF_E_ARG, "obstacle arrays missing");
-  if (rows == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
-  if (h->cfg.scalar == MRF_F64) {
-    using T = double;
-    return launch(h, mrf::k_rollout_cart_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0,
-                  (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0, (const T*)ov,
-                  (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
-  }
-  using T = float;
-  return launch(h, mrf::k_rollout_cart_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0,
-                (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0, (const T*)ov,
-                (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using CL = decltype(cl);
+    return launch(h, mrf::k_rollout_cart_panda<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows,
+                  (const T*)q0, (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0,
+                  (const T*)ov, (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  });
 }
 
 int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot, void* x_out, void* v_out,
@@ -757,17 +768,13 @@ int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot,
   if (rows == 0) return MRF_OK;
   if (rows < 0 || !q || !x_out) return fail(h, MRF_E_ARG, "null/negative argument");
   if ((v_out || a_out) && !qdot) return fail(h, MRF_E_ARG, "qdot required for v/a");
-  if (rows == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 block(64), grid((unsigned)((rows + 63) / 64));
-  if (h->cfg.scalar == MRF_F64) {
-    using T = double;
+  return dispatch_scalar(h, [&](auto t) {
+    using T = decltype(t);
     return launch(h, mrf::k_fk_spheres_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
                   (const T*)qdot, (T*)x_out, (T*)v_out, (T*)a_out);
-  }
-  using T = float;
-  return launch(h, mrf::k_fk_spheres_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
-                (const T*)qdot, (T*)x_out, (T*)v_out, (T*)a_out);
+  });
 }
 
 int mrf_step_predict(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, void* q_io,
@@ -775,21 +782,18 @@ int mrf_step_predict(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t
   MRF_CHECK_READY(h);
   if (h->cfg.model != MRF_MODEL_PANDA7 || h->cfg.mode != MRF_MODE_VEL)
     return fail(h, MRF_E_CONFIG, "sharded rollout needs the panda7 model in mode 'vel'");
+  if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || robot_first < 0 || robot_count < 1 || robot_first + robot_count > h->cfg.n_robots || !q_io ||
       !qdot || !sph_own)
     return fail(h, MRF_E_ARG, "bad argument");
-  if (n_scen == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = n_scen * robot_count;
   dim3 block(64), grid((unsigned)((rows + 63) / 64));
-  if (h->cfg.scalar == MRF_F64) {
-    using T = double;
+  return dispatch_scalar(h, [&](auto t) {
+    using T = decltype(t);
     return launch(h, mrf::k_step_predict<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
                   (int)robot_count, (T*)q_io, (const T*)qdot, (T*)sph_own);
-  }
-  using T = float;
-  return launch(h, mrf::k_step_predict<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
-                (int)robot_count, (T*)q_io, (const T*)qdot, (T*)sph_own);
+  });
 }
 
 int mrf_step_action(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
@@ -797,21 +801,20 @@ int mrf_step_action(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t 
   MRF_CHECK_READY(h);
   if (h->cfg.model != MRF_MODEL_PANDA7 || h->cfg.mode != MRF_MODE_VEL)
     return fail(h, MRF_E_CONFIG, "sharded rollout needs the panda7 model in mode 'vel'");
+  if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || robot_first < 0 || robot_count < 1 || robot_first + robot_count > h->cfg.n_robots || !q ||
       !qdot_io || !params || !sph_all || !sumsq_io)
     return fail(h, MRF_E_ARG, "bad argument");
-  if (n_scen == 0) return MRF_OK;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = n_scen * robot_count;
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
-  if (h->cfg.scalar == MRF_F64) {
-    using T = double;
-    return launch(h, mrf::k_step_action<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
-                  (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all, (T*)sumsq_io);
-  }
-  using T = float;
-  return launch(h, mrf::k_step_action<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first,
-                (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all, (T*)sumsq_io);
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using CL = decltype(cl);
+    return launch(h, mrf::k_step_action<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+                  (int)robot_first, (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all,
+                  (T*)sumsq_io);
+  });
 }
 
 }  // extern "C"
