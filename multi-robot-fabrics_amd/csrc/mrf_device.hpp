@@ -65,28 +65,47 @@ __device__ __forceinline__ void m_sincos(float x, float* s, float* c) { ::sincos
 // distances, radii, metrics -- O(1e-6 .. 1e12)).  The parity tolerance is 1e-9; tests/test_gpu_parity.py
 // checks both against correctly rounded division.
 __device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
+  double y = __builtin_amdgcn_rcp(x);  // 24-bit seed (4.5e-8 measured, tools/seed_accuracy.hip)
   double e = __builtin_fma(-x, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-x, y, 1.0);
-  return __builtin_fma(y, e, y);
+  return __builtin_fma(y, e, y);       // 2e-15
 }
-__device__ __forceinline__ float fast_rcp(float x) {
-  float y = __builtin_amdgcn_rcpf(x);
-  float e = __builtin_fmaf(-x, y, 1.0f);
-  return __builtin_fmaf(y, e, y);
-}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // 9e-8 measured
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
+  double y = __builtin_amdgcn_rsq(x);  // 5.2e-8 measured
   double e = __builtin_fma(-x * y, y, 1.0);
-  y = __builtin_fma(y, 0.5 * e, y);
-  e = __builtin_fma(-x * y, y, 1.0);
-  return __builtin_fma(y, 0.5 * e, y);
+  return __builtin_fma(y, 0.5 * e, y);  // 4e-15
 }
-__device__ __forceinline__ float fast_rsqrt(float x) {
-  float y = __builtin_amdgcn_rsqf(x);
-  float e = __builtin_fmaf(-x * y, y, 1.0f);
-  return __builtin_fmaf(y, 0.5f * e, y);
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // 9.3e-8 measured
+
+// exp for |x| < 700 without the overflow / subnormal paths of the library version (all arguments here are
+// bounded: -(a r)^2, -s x with x a barrier distance, tanh arguments): x = n ln2 + r, Taylor to r^12 (|r| <= 0.35).
+__device__ __forceinline__ double fast_exp(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(-n, 0.6931471803691238, x);
+  r = __builtin_fma(-n, 1.9082149292705877e-10, r);
+  double p = 1.0 / 479001600.0;
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+// tanh(x) = sign(x) (1 - t)/(1 + t), t = exp(-2|x|) <= 1: absolute error ~1e-16 (the relative error near 0 does
+// not matter at the call sites: attractor force ~ tanh(a r) x/r, damper switches ~ tanh(O(1)))
+template <typename T>
+__device__ __forceinline__ T fast_tanh(T x) {
+  const T t = fast_exp(T(-2) * (x < T(0) ? -x : x));
+  const T v = (T(1) - t) * fast_rcp(T(1) + t);
+  return x < T(0) ? -v : v;
 }
 
 // sin/cos of a small angle |d| < 0.125 by Taylor series (truncation < 3e-18): used to advance cos q, sin q by
@@ -150,7 +169,7 @@ __device__ __forceinline__ T leaf_coeff(const LeafFn<T>& f, T x, T ix, T xd) {
   if (f.family == MRF_FAMILY_POW)
     v = f.k * powi(ix, f.p);
   else
-    v = f.k * (fast_rcp(T(1) + f.c * m_exp(-f.s * x)) - T(1));
+    v = f.k * (fast_rcp(T(1) + f.c * fast_exp(-f.s * x)) - T(1));
   return v * g;
 }
 
@@ -161,6 +180,49 @@ __device__ __forceinline__ void scalar_leaf(const LeafFn<T>& geo, const LeafFn<T
   m = T(2) * leaf_coeff(fin, x, ix, xd);
   f = m * leaf_coeff(geo, x, ix, xd) * xd * xd;
 }
+
+// Compile-time scalar leaves (plane and joint-limit leaves).  SLeaf<FAMG,PG,GG,PL,GL>: geometry of family FAMG
+// (POW exponent PG or LOGISTIC) with gate GG, Finsler k/x^PL with gate GL; constants k, c, s stay runtime.
+struct SLeafGeneric {
+  static constexpr bool generic = true;
+};
+template <int FAMG, int PG, int GG, int PL, int GL>
+struct SLeaf {
+  static constexpr bool generic = false;
+  static constexpr int famg = FAMG, pg = PG, gg = GG, pl = PL, gl = GL;
+};
+
+template <int P, typename T>
+__device__ __forceinline__ T cpow(T x) {  // x^P, P compile-time
+  if constexpr (P == 0) return T(1);
+  else if constexpr (P == 1) return x;
+  else if constexpr (P % 2 == 0) { T h = cpow<P / 2>(x); return h * h; }
+  else return x * cpow<P - 1>(x);
+}
+
+template <class SL, typename T>
+__device__ __forceinline__ void scalar_leaf_t(const LeafFn<T>& geo, const LeafFn<T>& fin, T x, T xd, T& m, T& f) {
+  if constexpr (SL::generic) {
+    scalar_leaf(geo, fin, x, xd, m, f);
+  } else {
+    const T ix = fast_rcp(x);
+    m = T(2) * fin.k * gate_value<T>(SL::gl, xd) * cpow<SL::pl>(ix);
+    T hc;
+    if constexpr (SL::famg == MRF_FAMILY_POW)
+      hc = geo.k * cpow<SL::pg>(ix);
+    else
+      hc = geo.k * (fast_rcp(T(1) + geo.c * fast_exp(-geo.s * x)) - T(1));
+    f = m * (hc * gate_value<T>(SL::gg, xd)) * xd * xd;
+  }
+}
+
+// A leaf set = the compile-time shape of the three barrier leaf classes of a planner.
+template <class C, class P, class L>
+struct LeafSet {
+  using Collision = C;
+  using Plane = P;
+  using Limit = L;
+};
 
 // ------------------------------------------------------------------------------------ Panda chain
 // panda_joint1..7 origins (URDF panda_with_finger.urdf:98-107,150-158,201-209,253-261,326-334,378-386,451-459)
@@ -267,11 +329,14 @@ __device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T
   T off_s[3] = {cfg.sphere_off[0][0], cfg.sphere_off[0][1], cfg.sphere_off[0][2]};
 #pragma unroll 1
   for (int j = 0; j < 8; ++j) {
-    T r[3];
-    const T px = T(kPX[j]), py = T(kPY[j]), pz = T(kPZ[j]);
+    // wave-uniform joint constants by scalar selects (no table load on the critical path of the single wave)
+    const T px = j == 3 ? T(0.0825) : (j == 4 ? T(-0.0825) : (j == 6 ? T(0.088) : T(0)));
+    const T py = j == 2 ? T(-0.316) : (j == 4 ? T(0.384) : T(0));
+    const T pz = j == 0 ? T(0.333) : (j == 7 ? T(0.107) : T(0));
+    if (j != 1 && j != 5) {  // joints 2 and 6 have a zero origin offset
+      T r[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) r[k] = px * X[k] + py * Y[k] + pz * Z[k];
-    {
+      for (int k = 0; k < 3; ++k) r[k] = px * X[k] + py * Y[k] + pz * Z[k];
       T wr[3], wwr[3], ar[3];
       cross3(w, r, wr);
       cross3(w, wr, wwr);
@@ -284,7 +349,7 @@ __device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T
       }
     }
     if (j < 7) {
-      const int roll = kROLL[j];
+      const int roll = ((0x6C >> j) & 1) - ((0x12 >> j) & 1);  // +1: j = 2,3,5,6   -1: j = 1,4
       if (roll != 0) {
         const T sg = T(roll);
 #pragma unroll
@@ -386,14 +451,6 @@ struct LeafPow {
   static_assert(PL >= 2 && PG >= 1, "LeafPow needs PL >= 2 and PG >= 1");
 };
 
-template <int P, typename T>
-__device__ __forceinline__ T cpow(T x) {  // x^P, P compile-time
-  if constexpr (P == 0) return T(1);
-  else if constexpr (P == 1) return x;
-  else if constexpr (P % 2 == 0) { T h = cpow<P / 2>(x); return h * h; }
-  else return x * cpow<P - 1>(x);
-}
-
 // weights of one spherical-obstacle leaf:  wm = m/R^2,  wf = f/R   (d = distance, nv = n.v_rel, R = r_o + r_b)
 template <class CL, typename T>
 __device__ __forceinline__ void collision_weights(const DevCfg<T>& cfg, T d, T nv, T R, T& wm, T& fR) {
@@ -454,7 +511,7 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
 }
 
 // plane-constraint leaves of all ego points:  x = |a.p + d|/|a| - r_body
-template <typename T, int NP>
+template <class SL, typename T, int NP>
 __device__ __forceinline__ void accumulate_plane(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* con,
                                                  EgoAcc<T, NP>& acc) {
   T ina = fast_rsqrt(con[0] * con[0] + con[1] * con[1] + con[2] * con[2]);
@@ -471,7 +528,7 @@ __device__ __forceinline__ void accumulate_plane(const DevCfg<T>& cfg, const Ego
       if (l < E.nl[g]) {
         T x = sg * val - E.rb[g][l];
         T m, f;
-        scalar_leaf(cfg.pg, cfg.pf, x, xd, m, f);
+        scalar_leaf_t<SL>(cfg.pg, cfg.pf, x, xd, m, f);
         wM += m;
         wf += f;
       }
@@ -574,9 +631,9 @@ __device__ __forceinline__ void attractor(const DevCfg<T>& cfg, const T* x, T w,
   T r = m_sqrt(r2);
   rnorm = r;
   T ar = cfg.attr_a * r;
-  twoA = T(2) * ((cfg.attr_mu - cfg.attr_ml) * m_exp(-ar * ar) + cfg.attr_ml);
+  twoA = T(2) * ((cfg.attr_mu - cfg.attr_ml) * fast_exp(-ar * ar) + cfg.attr_ml);
   // grad psi = w k tanh(alpha r) x/r ; 0 at r == 0 (build convention, DESIGN.md "deviations")
-  T g = r > T(0) ? w * cfg.attr_k * m_tanh(cfg.attr_alpha * r) * fast_rcp(r) : T(0);
+  T g = r > T(0) ? w * cfg.attr_k * fast_tanh(cfg.attr_alpha * r) * fast_rcp(r) : T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) f[k] = twoA * g * x[k];
 }
@@ -596,9 +653,9 @@ __device__ __forceinline__ void finish(const DevCfg<T>& cfg, const T (&qd)[N], b
 #pragma unroll
     for (int j = 0; j < N; ++j) qh += qd[j] * hf[j];
     T alpha_f = -qh * fast_rcp(cfg.eps + qq);
-    T eta = T(0.5) * (m_tanh(-cfg.eta_a * qq - cfg.eta_s) + T(1));
+    T eta = T(0.5) * (fast_tanh(-cfg.eta_a * qq - cfg.eta_s) + T(1));
     T a_ex = eta * alpha_g + (T(1) - eta) * alpha_f;
-    T beta = T(0.5) * (m_tanh(-cfg.beta_a * (xpsi - cfg.beta_r)) + T(1)) * cfg.beta_b + cfg.beta_s +
+    T beta = T(0.5) * (fast_tanh(-cfg.beta_a * (xpsi - cfg.beta_r)) + T(1)) * cfg.beta_b + cfg.beta_s +
              m_max(T(0), alpha_g - a_ex);
 #pragma unroll
     for (int j = 0; j < N; ++j) qdd[j] = -hf[j] - (a_ex + beta) * qd[j];
@@ -659,7 +716,7 @@ __device__ __forceinline__ void panda_ego_points(const PandaKin<T>& K, const PRM
 }
 
 // Everything after the obstacle loop: plane + pullbacks + limits + attractors + solves + damping.
-template <typename T, class PRM>
+template <class LS, typename T, class PRM>
 __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const PandaState<T>& R, const PRM& prm,
                                                  const PandaKin<T>& K, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc,
                                                  T (&qdd)[7], T (&act)[7]) {
@@ -670,7 +727,7 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
   if (cfg.n_ego > 0) {
     if (cfg.n_planes > 0) {
       T con[4] = {prm[MRF_P_CONSTRAINT_0], prm[MRF_P_CONSTRAINT_0 + 1], prm[MRF_P_CONSTRAINT_0 + 2], prm[MRF_P_CONSTRAINT_0 + 3]};
-      accumulate_plane(cfg, E, con, acc);
+      accumulate_plane<typename LS::Plane>(cfg, E, con, acc);
     }
     constexpr int jo[4] = {2, 3, 4, 6};
     // t = b + A c with c = jsign * Jdot qd of the point
@@ -693,10 +750,10 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       T m, f;
-      scalar_leaf(cfg.lg, cfg.lf, R.q[j] - cfg.limits[j][0], R.qd[j], m, f);
+      scalar_leaf_t<typename LS::Limit>(cfg.lg, cfg.lf, R.q[j] - cfg.limits[j][0], R.qd[j], m, f);
       S.M[tri<7>(j, j)] += m;
       S.f[j] += f;
-      scalar_leaf(cfg.lg, cfg.lf, cfg.limits[j][1] - R.q[j], -R.qd[j], m, f);
+      scalar_leaf_t<typename LS::Limit>(cfg.lg, cfg.lf, cfg.limits[j][1] - R.q[j], -R.qd[j], m, f);
       S.M[tri<7>(j, j)] += m;
       S.f[j] -= f;
     }
@@ -772,7 +829,7 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
 // walked twice: once for the ego points the obstacle loop needs (positions, velocities), once afterwards for the
 // joint axes / origins / curvature terms of the pullback -- recomputing ~300 flops is cheaper than keeping
 // ~60 more values live across the loop (register pressure is what limits these kernels).
-template <typename T, class PRM, class Obst>
+template <class LS, typename T, class PRM, class Obst>
 __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* __restrict__ mount, const PandaState<T>& R,
                                                 const PRM& prm, Obst obstacles, T (&qdd)[7], T (&act)[7]) {
   EgoPts<T, NG> E;
@@ -792,7 +849,7 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
   }
   PandaKin<T> K;
   panda_walk_own<T>(mount, R2.cq, R2.sq, R2.qd, K);
-  panda_finish_row(cfg, R, prm, K, E, acc, qdd, act);
+  panda_finish_row<LS>(cfg, R, prm, K, E, acc, qdd, act);
 }
 
 // ------------------------------------------------------------------------------------ planar point robot

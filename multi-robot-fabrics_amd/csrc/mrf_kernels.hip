@@ -55,7 +55,7 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
 }
 
 // ---------------------------------------------------------------------------- compute_action
-template <typename T, class CL>
+template <typename T, class LS>
 __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                        const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ prm, int n_obst, int n_static,
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restric
   load_state(rows, r, q, qd, R);
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   T qdd[7], act[7];
-  panda_solve_row(
+  panda_solve_row<LS>(
       cfg, cfg.mount[(int)(r % cfg.n_robots)], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-        obstacles_from_arrays<CL>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E, acc);
+        obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E, acc);
       },
       qdd, act);
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 // exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
 // stays inside the wave: each lane publishes cos q, sin q, qdot of its 7 joints to a 21 x 64 LDS tile and
 // re-walks the other robots' chains from that tile, streaming their spheres straight into its leaf sums.
-template <typename T, class CL>
+template <typename T, class LS>
 __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
     }
     __syncthreads();
     T qdd[7], act[7];
-    panda_solve_row(
+    panda_solve_row<LS>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
 #pragma unroll 1
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                     vv[c] = cfg.dynamic ? v[c] : T(0);              // FPJ:215-220
                     aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);  // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
                   }
-                  accumulate_obstacle<CL>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
+                  accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
                 });
           }
         },
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
 }
 
 // ---------------------------------------------------------------------------- Cartesian rollout
-template <typename T, class CL>
+template <typename T, class LS>
 __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
                                                              const T* __restrict__ prm, int n_obst, int n_static,
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __r
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
     T qdd[7], act[7];
-    panda_solve_row(
+    panda_solve_row<LS>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          obstacles_from_arrays<CL>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc);
+          obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc);
         },
         qdd, act);
 #pragma unroll
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
 }
 
 // action: fabric solve of the owned robots against every other robot's published spheres.
-template <typename T, class CL>
+template <typename T, class LS>
 __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
                                                       int robot_count, const T* __restrict__ q, T* __restrict__ qd_io,
                                                       const T* __restrict__ prm, const T* __restrict__ sph_all,
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   const int N = cfg.n_robots, S = cfg.n_spheres;
   T qdd[7], act[7];
-  panda_solve_row(
+  panda_solve_row<LS>(
       cfg, cfg.mount[me], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
 #pragma unroll 1
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
               v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
               a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
             }
-            accumulate_obstacle<CL>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc);
+            accumulate_obstacle<typename LS::Collision>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc);
           }
         }
       },
@@ -562,12 +562,22 @@ int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args.
   return check_hip(h, hipGetLastError(), "kernel launch");
 }
 
-// the reference's Panda collision strings (EXJ:88-89) get the compile-time leaf policy, anything else the generic one
-using LeafPanda = mrf::LeafPow<4, 4, MRF_GATE_NONE, MRF_GATE_NONE>;
-bool is_panda_leaf(const mrf_config& c) {
-  const mrf_leaf_fn &g = c.collision_geometry, &f = c.collision_finsler;
-  return g.family == MRF_FAMILY_POW && f.family == MRF_FAMILY_POW && g.p == 4 && f.p == 4 &&
-         g.gate == MRF_GATE_NONE && f.gate == MRF_GATE_NONE;
+// the reference's Panda leaf strings (EXJ:87-89 + the library's limit / plane-Finsler defaults) get compile-time
+// leaf policies; any other configuration runs the generic (runtime-family) instantiation
+using LeafSetPanda = mrf::LeafSet<mrf::LeafPow<4, 4, MRF_GATE_NONE, MRF_GATE_NONE>,
+                                  mrf::SLeaf<MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE, 1, MRF_GATE_NEG>,
+                                  mrf::SLeaf<MRF_FAMILY_POW, 1, MRF_GATE_NONE, 1, MRF_GATE_NEG>>;
+using LeafSetGeneric = mrf::LeafSet<mrf::LeafGeneric, mrf::SLeafGeneric, mrf::SLeafGeneric>;
+bool leaf_is(const mrf_leaf_fn& f, int family, int p, int gate) {
+  return f.family == family && f.gate == gate && (family == MRF_FAMILY_LOGISTIC || f.p == p);
+}
+bool is_panda_leafset(const mrf_config& c) {
+  return leaf_is(c.collision_geometry, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
+         leaf_is(c.collision_finsler, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
+         leaf_is(c.plane_geometry, MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE) &&
+         leaf_is(c.plane_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG) &&
+         leaf_is(c.limit_geometry, MRF_FAMILY_POW, 1, MRF_GATE_NONE) &&
+         leaf_is(c.limit_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG);
 }
 
 template <typename F>
@@ -576,9 +586,9 @@ int dispatch_scalar(mrf_handle* h, F f) {
 }
 template <typename F>
 int dispatch(mrf_handle* h, F f) {
-  const bool fast = is_panda_leaf(h->cfg);
-  if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafPanda{}) : f(double{}, mrf::LeafGeneric{});
-  return fast ? f(float{}, LeafPanda{}) : f(float{}, mrf::LeafGeneric{});
+  const bool fast = is_panda_leafset(h->cfg);
+  if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafSetPanda{}) : f(double{}, LeafSetGeneric{});
+  return fast ? f(float{}, LeafSetPanda{}) : f(float{}, LeafSetGeneric{});
 }
 
 }  // namespace
@@ -714,8 +724,8 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
     });
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
-    using CL = decltype(cl);
-    return launch(h, mrf::k_action_panda<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
+    using LS = decltype(cl);
+    return launch(h, mrf::k_action_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
                   (const T*)qdot, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov,
                   (const T*)oa, (const T*)orad, (T*)qddot_out, (T*)action_out);
   });
@@ -735,8 +745,8 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
-    using CL = decltype(cl);
-    return launch(h, mrf::k_rollout_panda<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+    using LS = decltype(cl);
+    return launch(h, mrf::k_rollout_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
                   (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
   });
 }
@@ -754,8 +764,8 @@ int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const voi
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
-    using CL = decltype(cl);
-    return launch(h, mrf::k_rollout_cart_panda<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows,
+    using LS = decltype(cl);
+    return launch(h, mrf::k_rollout_cart_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows,
                   (const T*)q0, (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0,
                   (const T*)ov, (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
   });
@@ -810,8 +820,8 @@ int mrf_step_action(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t 
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
-    using CL = decltype(cl);
-    return launch(h, mrf::k_step_action<T, CL>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+    using LS = decltype(cl);
+    return launch(h, mrf::k_step_action<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
                   (int)robot_first, (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all,
                   (T*)sumsq_io);
   });
