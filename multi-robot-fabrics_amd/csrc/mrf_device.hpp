@@ -317,16 +317,23 @@ __device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, cons
 // Rolled walk of a robot whose spheres are wanted: emits (x, v, Jdot qd) of every configured sphere, in
 // table order, to `emit(s, x, v, a)`.  State is a handful of named vectors, so the loop over joints stays
 // rolled and the consumer is instantiated once.  get(j, c, s, qd) supplies cos q_j, sin q_j, qdot_j.
-template <typename T, typename Get, typename Emit>
+// LINK_ORIGINS = true is the reference's rollout table (one sphere at the origin of each of the 8 links,
+// PM:25-26): the sphere of link j+1 is emitted right after joint j, with no inner loop and no table reads.
+template <bool LINK_ORIGINS, typename T, typename Get, typename Emit>
 __device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T* __restrict__ mount, Get get,
                                                    Emit emit) {
   T X[3] = {mount[0], mount[4], mount[8]}, Y[3] = {mount[1], mount[5], mount[9]}, Z[3] = {mount[2], mount[6], mount[10]};
   T o[3] = {mount[3], mount[7], mount[11]};
   T w[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)}, vo[3] = {T(0), T(0), T(0)}, ao[3] = {T(0), T(0), T(0)};
   int s = 0;
-  const int S = cfg.n_spheres;
-  int link_s = S > 0 ? cfg.sphere_link[0] : 0;
-  T off_s[3] = {cfg.sphere_off[0][0], cfg.sphere_off[0][1], cfg.sphere_off[0][2]};
+  const int S = LINK_ORIGINS ? 8 : cfg.n_spheres;
+  int link_s = (!LINK_ORIGINS && S > 0) ? cfg.sphere_link[0] : 0;
+  T off_s[3] = {T(0), T(0), T(0)};
+  if (!LINK_ORIGINS) {
+    off_s[0] = cfg.sphere_off[0][0];
+    off_s[1] = cfg.sphere_off[0][1];
+    off_s[2] = cfg.sphere_off[0][2];
+  }
 #pragma unroll 1
   for (int j = 0; j < 8; ++j) {
     // wave-uniform joint constants by scalar selects (no table load on the critical path of the single wave)
@@ -375,6 +382,10 @@ __device__ __forceinline__ void panda_walk_spheres(const DevCfg<T>& cfg, const T
         al[k] += qdj * wz[k];
         w[k] += qdj * Z[k];
       }
+    }
+    if (LINK_ORIGINS) {
+      emit(j, o, vo, ao);
+      continue;
     }
     // spheres attached to panda_link(j+1): frame (X,Y,Z,o), angular state (w, al) of that link.
     // The table entry of the *next* sphere is fetched before the current one is consumed, so the scalar-load

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 // exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
 // stays inside the wave: each lane publishes cos q, sin q, qdot of its 7 joints to a 21 x 64 LDS tile and
 // re-walks the other robots' chains from that tile, streaming their spheres straight into its leaf sums.
-template <typename T, class LS>
+template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
             int jr = li + d;
             if (jr >= N) jr -= N;
             const int src = ls * N + jr;
-            panda_walk_spheres<T>(
+            panda_walk_spheres<LO, T>(
                 cfg, cfg.mount[jr],
                 [&](int j, T& c, T& s, T& qdj) {
                   c = xch[(3 * j + 0) * 64 + src];
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void k_fk_spheres_panda(const DevCfg<T>* __rest
     xch[(3 * j + 2) * 64 + lane] = qd ? qd[j * rows + r] : T(0);
   }
   __syncthreads();
-  panda_walk_spheres<T>(
+  panda_walk_spheres<false, T>(
       cfg, cfg.mount[(int)(r % cfg.n_robots)],
       [&](int j, T& c, T& s, T& qdj) {
         c = xch[(3 * j + 0) * 64 + lane];
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
   }
   __syncthreads();
   const int S = cfg.n_spheres;
-  panda_walk_spheres<T>(
+  panda_walk_spheres<false, T>(
       cfg, cfg.mount[robot_first + lr],
       [&](int j, T& c, T& s, T& qdj) {
         c = xch[(3 * j + 0) * 64 + lane];
@@ -580,6 +580,16 @@ bool is_panda_leafset(const mrf_config& c) {
          leaf_is(c.limit_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG);
 }
 
+// the reference's rollout sphere table: the origins of panda_link1..8 (PM:25-26)
+bool is_link_origin_table(const mrf_config& c) {
+  if (c.n_spheres != 8) return false;
+  for (int s = 0; s < 8; ++s)
+    if (c.sphere_link[s] != s + 1 || c.sphere_offset[s][0] != 0.0 || c.sphere_offset[s][1] != 0.0 ||
+        c.sphere_offset[s][2] != 0.0)
+      return false;
+  return true;
+}
+
 template <typename F>
 int dispatch_scalar(mrf_handle* h, F f) {
   return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
@@ -746,7 +756,10 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
-    return launch(h, mrf::k_rollout_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+    if (is_link_origin_table(h->cfg))
+      return launch(h, mrf::k_rollout_panda<T, LS, true>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+                    (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+    return launch(h, mrf::k_rollout_panda<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
                   (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
   });
 }
