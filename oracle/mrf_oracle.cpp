@@ -499,9 +499,11 @@ int mrfo_compute_action(const mrf_config* cfg, int64_t rows, const double* q, co
                         int32_t n_obst, int32_t n_static, const double* ox, const double* ov, const double* oa, const double* orad,
                         double* qddot_out, double* action_out) {
   const int n = dof_of(*cfg);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+  {
+  std::vector<Obst> obst(n_obst);  // one scratch list per thread
+#pragma omp for schedule(static)
   for (int64_t r = 0; r < rows; ++r) {
-    std::vector<Obst> obst(n_obst);
     double qv[DOF_MAX], qdv[DOF_MAX], prm[MRF_NPARAM], qdd[DOF_MAX], act[DOF_MAX];
     for (int j = 0; j < n; ++j) {
       qv[j] = q[j * rows + r];
@@ -525,6 +527,7 @@ int mrfo_compute_action(const mrf_config* cfg, int64_t rows, const double* q, co
       if (qddot_out) qddot_out[j * rows + r] = qdd[j];
       action_out[j * rows + r] = act[j];
     }
+  }
   }
   return 0;
 }
@@ -590,9 +593,11 @@ int mrfo_rollout(const mrf_config* cfg, int64_t n_scen, const double* q0, const 
   const int n = dof_of(*cfg), N = cfg->n_robots, S = cfg->n_spheres, H = cfg->horizon;
   const int64_t rows = n_scen * N;
   if (cfg->mode != MRF_MODE_VEL) return -2;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+  {
+  std::vector<Obst> obst((size_t)S * (N - 1));  // one scratch list per thread
+#pragma omp for schedule(static)
   for (int64_t sc = 0; sc < n_scen; ++sc) {
-    std::vector<Obst> obst((size_t)S * (N - 1));
     double q[MRF_MAX_ROBOTS][DOF_MAX], qd[MRF_MAX_ROBOTS][DOF_MAX];
     double prm[MRF_MAX_ROBOTS][MRF_NPARAM], sumsq[MRF_MAX_ROBOTS];
     for (int i = 0; i < N; ++i) {
@@ -649,6 +654,7 @@ int mrfo_rollout(const mrf_config* cfg, int64_t n_scen, const double* q0, const 
     }
     for (int i = 0; i < N; ++i) avg_out[sc * N + i] = sumsq[i] / (double)(H * n);
   }
+  }
   return 0;
 }
 
@@ -658,9 +664,11 @@ int mrfo_rollout_cartesian(const mrf_config* cfg, int64_t rows, const double* q0
                            const double* params, int32_t n_obst, int32_t n_static, const double* ox0, const double* ov, const double* oa,
                            const double* orad, double* avg_out, double* traj_q, double* traj_qd) {
   const int n = dof_of(*cfg), H = cfg->horizon;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel
+  {
+  std::vector<Obst> obst(n_obst);  // one scratch list per thread
+#pragma omp for schedule(static)
   for (int64_t r = 0; r < rows; ++r) {
-    std::vector<Obst> obst(n_obst);
     double q[DOF_MAX], qd[DOF_MAX], prm[MRF_NPARAM], qdd[DOF_MAX], act[DOF_MAX];
     for (int j = 0; j < n; ++j) {
       q[j] = q0[j * rows + r];
@@ -696,6 +704,7 @@ int mrfo_rollout_cartesian(const mrf_config* cfg, int64_t rows, const double* q0
         for (int c = 0; c < 3; ++c) obst[m].x[c] += cfg->dt * obst[m].v[c];
     }
     avg_out[r] = sumsq / (double)(H * n);
+  }
   }
   return 0;
 }
