@@ -96,6 +96,9 @@ def load_library(path=None):
         raise MrfLibraryError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback for the fabric solve.")
+    # torch ships its own libamdhip64; load it first so that this library binds to the same HIP runtime the
+    # tensors live in (two runtimes in one process do not see each other's devices / allocations)
+    import torch  # noqa: F401
     lib = C.CDLL(p)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.mrf_default_config_panda.argtypes = [C.POINTER(Config), i32, i32]

@@ -219,3 +219,33 @@ def test_robot_groups_and_partition():
             parts = sharded.robot_partition(n, g)
             assert sum(c for _, c in parts) == n and all(c >= 1 for _, c in parts)
             assert [f for f, _ in parts] == list(np.cumsum([0] + [c for _, c in parts[:-1]]))
+
+
+# ------------------------------------------------------------------------------------------ deadlock logic (DP:50-118)
+def test_deadlock_checking_known_answers():
+    from multi_robot_fabrics_amd.deadlock import deadlockprevention
+    dp = deadlockprevention([7, 7], 2, 10)
+    x = [np.array([0.5, 0.0, 1.0]), np.array([0.6, 0.1, 1.0])]
+    goals = [np.array([0.2, 0.6, 1.15]), np.array([0.8, -0.6, 1.15])]
+    weights = [2.0, 2.0]
+    # moving robots: nothing happens, the wait counter keeps its "idle" value
+    g, w, t = dp.deadlock_checking(x, list(goals), list(weights), time_step=50, time_deadlock_out=1000, avg_sum=0.5,
+                                   state_machine_robots=[0, 0])
+    assert w == [2.0, 2.0] and t == 1000 and np.array_equal(g[1], goals[1])
+    # stalled, close end-effectors, both approaching: robot 0 is closer to its goal -> leader (weight 3), robot 1 backs off
+    g, w, t = dp.deadlock_checking(x, list(goals), list(weights), time_step=50, time_deadlock_out=1000, avg_sum=0.01,
+                                   state_machine_robots=[0, 1])
+    d0, d1 = np.linalg.norm(x[0] - goals[0]), np.linalg.norm(x[1] - goals[1])
+    lead, foll = (0, 1) if d0 <= d1 else (1, 0)
+    assert t == 0 and w[lead] == 3 and w[foll] == 2
+    diff = (x[lead] - x[foll]) * 2
+    assert np.allclose(g[foll], x[foll] - 0.3 / np.linalg.norm(diff) * diff)
+    # afterwards the rewritten goal is held for time_wait steps
+    g2, w2, t2 = dp.deadlock_checking(x, list(goals), list(weights), time_step=51, time_deadlock_out=t, avg_sum=0.5,
+                                      state_machine_robots=[0, 1])
+    assert t2 == 1 and w2[lead] == 3 and np.allclose(g2[foll], g[foll])
+    # too early in the episode (time_step <= 10): never a deadlock
+    dp2 = deadlockprevention([7, 7, 7], 3, 10)
+    g3, w3, t3 = dp2.deadlock_checking(x + [np.array([2.0, 2.0, 1.0])], list(goals) + [np.zeros(3)], [2.0] * 3, time_step=5,
+                                       time_deadlock_out=1000, avg_sum=0.0, state_machine_robots=[0, 0, 0])
+    assert w3 == [2.0] * 3 and t3 == 1000
