@@ -3,9 +3,8 @@
 
 One "step" = one control step of every scenario in the batch, inputs resident in HBM:
     (1) coupled Rollout-Fabrics over H steps for all N robots  -> avg velocity per robot   [mrf_rollout]
-    (2) sphere kinematics of every robot at the current state                              [mrf_fk_spheres]
-    (3) per-robot obstacle assembly (the spheres of the other robots, EXJ:394-412)         [device gather]
-    (4) one compute_action per robot                                                       [mrf_compute_action]
+    (2) one compute_action per robot against the other robots' collision spheres, with the obstacle assembly of
+        the reference's loop (x from FK, v = J qdot, a = 0; EXJ:394-448) done on chip      [mrf_compute_action_coupled]
 value = control-steps/s over all ranks (scenarios are sharded across GPUs, weak scaling, no collective on the
 data path); `rollout_steps_per_s` = robot x horizon-step fabric evaluations per second.  With --shard robots
 the north-star partitioning is timed instead: one robot (or a contiguous group) per GPU with an RCCL all-gather
@@ -87,16 +86,9 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
 def single_scenario_latency(h_roll, h_act, batch, N, S, iters=200):
     """B = 1: what a real-time controller of one N-Panda cell sees per control step, action copied back to the host."""
     q, qd, prm = (h_roll.tensor(batch[k][:, :N]) for k in ("q", "qdot", "params"))
-    others = torch.tensor([[j for j in range(N) if j != i] for i in range(N)], device="cuda")
-    orad = torch.full(((N - 1) * S, N), 0.08, dtype=h_act.dtype, device="cuda")
-
-    def gather(sph):
-        return sph.view(S, 3, 1, N)[:, :, :, others].permute(4, 0, 1, 2, 3).reshape((N - 1) * S, 3, N).contiguous()
 
     def step():
-        avg = h_roll.rollout(q, qd, prm)
-        sx, sv, sa = h_act.fk_spheres(q, qd)
-        return avg, h_act.compute_action(q, qd, prm, gather(sx), gather(sv), gather(sa), orad)
+        return h_roll.rollout(q, qd, prm), h_act.compute_action_coupled(q, qd, prm, use_accel=False)
 
     for _ in range(20):
         step()
@@ -109,7 +101,7 @@ def single_scenario_latency(h_roll, h_act, batch, N, S, iters=200):
         ts.append(time.perf_counter() - t0)
     med = sorted(ts)[len(ts) // 2]
     return {"control_step_ms": 1e3 * med, "control_steps_per_s": 1.0 / med,
-            "note": "one scenario, host-synchronous: rollout + fk + gather + per-robot compute_action + D2H of the action"}
+            "note": "one scenario, host-synchronous: rollout + coupled compute_action + D2H of the action"}
 
 
 def main():
@@ -168,14 +160,6 @@ def main():
     h_act = FabricHandle(cfg_act, local_rank)
     q, qd, prm = (h_roll.tensor(batch[k]) for k in ("q", "qdot", "params"))
     rows = B * N
-    # obstacle gather plan: for robot i the spheres of robots j != i, in robot order
-    others = torch.tensor([[j for j in range(N) if j != i] for i in range(N)], device="cuda")  # [N, N-1]
-    orad = torch.full(((N - 1) * S, rows), 0.08, dtype=h_act.dtype, device="cuda")
-
-    def gather(sph):  # [S,3,rows] -> [(N-1)*S, 3, rows]
-        g = sph.view(S, 3, B, N)[:, :, :, others]            # [S,3,B,N,N-1]
-        return g.permute(4, 0, 1, 2, 3).reshape((N - 1) * S, 3, rows).contiguous()
-
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def control_step(k=None):
@@ -184,8 +168,7 @@ def main():
         avg = h_roll.rollout(q, qd, prm)
         if k is not None:
             ev[k][1].record()
-        sx, sv, sa = h_act.fk_spheres(q, qd)
-        act = h_act.compute_action(q, qd, prm, gather(sx), gather(sv), gather(sa), orad)
+        act = h_act.compute_action_coupled(q, qd, prm, use_accel=False)
         return avg, act
 
     def barrier():
@@ -229,7 +212,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{N}-Panda RF-CV H={H}: coupled jointspace rollout (S={S} spheres/robot) + "
-                                   f"compute_action with M={(N - 1) * S} dynamic obstacle spheres per robot",
+                                   f"compute_action against the M={(N - 1) * S} spheres of the other robots",
                        "scenarios_per_gpu": B, "robots": N, "horizon": H, "spheres_per_robot": S,
                        "sharding": "scenarios (independent, no collective)"},
             "rollout_steps_per_s": world * units * args.steps / elapsed,

@@ -136,6 +136,14 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
                        int32_t n_obst, int32_t n_obst_static, const void* obst_x, const void* obst_v, const void* obst_a,
                        const void* obst_r, void* qddot_out, void* action_out, void* stream);
 
+/* compute_action for all robots of n_scenarios scenarios with the host-side obstacle assembly of the control loop
+ * (example_pandas_Jointspace.py:394-412) done on the device: the dynamic obstacles of robot i are the configured
+ * spheres (cfg.sphere_*) of every other robot of its scenario -- x from forward kinematics, v = J qdot
+ * (zero when cfg.dynamic == 0, EXJ:336-337), a = 0 as the reference passes it (EXJ:411) or, with use_accel != 0,
+ * jac_dot*qdot as in the rollouts (FPJ:97-99).  Arrays as mrf_compute_action, rows = n_scenarios * n_robots. */
+int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scenarios, const void* q, const void* qdot,
+                               const void* params, int32_t use_accel, void* qddot_out, void* action_out, void* stream);
+
 /* Replaces ForwardFabricsPlanner.get_velocity_rollouts / rollouts_numerical (FPJ:190-249,298-423):
  * the coupled N-robot, H-step joint-space rollout.  rows = n_scenarios * n_robots.
  *   q0, qdot0 [dof][rows]   params [MRF_NPARAM][rows]

@@ -75,7 +75,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
 
 EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
-    "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_rollout", "mrf_rollout_cartesian",
+    "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
     "mrf_fk_spheres", "mrf_step_predict", "mrf_step_action",
 ]
 
@@ -117,6 +117,8 @@ def load_library(path=None):
     lib.mrf_config_sizeof.restype = C.c_int64
     lib.mrf_compute_action.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mrf_compute_action.restype = C.c_int
+    lib.mrf_compute_action_coupled.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp]
+    lib.mrf_compute_action_coupled.restype = C.c_int
     lib.mrf_rollout.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.mrf_rollout.restype = C.c_int
     lib.mrf_rollout_cartesian.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -249,6 +249,77 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
   if (active) avg_out[row] = sumsq / (T)(H * 7);  // FPJ:102-116
 }
 
+// ---------------------------------------------------------------------------- coupled compute_action
+// One control step's compute_action for every robot of every scenario with the host-side obstacle assembly of the
+// reference's loop (EXJ:394-412) done on chip: the dynamic obstacles of robot i are the configured spheres of all
+// other robots of its scenario, x from FK, v = J qdot, a = 0 ("currently no acceleration", EXJ:411) or
+// jac_dot*qdot (use_accel).  Same wave layout and LDS exchange as the rollout kernel, no time stepping.
+template <typename T, class LS, bool LO>
+__global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
+                                                        const T* __restrict__ q, const T* __restrict__ qd,
+                                                        const T* __restrict__ prm, int use_accel,
+                                                        T* __restrict__ qdd_out, T* __restrict__ act_out) {
+  __shared__ T xch[21 * 64];
+  const DevCfg<T>& cfg = *cfgp;
+  const int N = cfg.n_robots;
+  const int spw = 64 / N;
+  const int lane = threadIdx.x;
+  int ls = lane / N;
+  const int li = lane - ls * N;
+  int64_t scen = (int64_t)blockIdx.x * spw + ls;
+  const bool active = ls < spw && scen < n_scen;
+  if (ls >= spw) ls = 0;
+  if (scen >= n_scen || !active) scen = (int64_t)blockIdx.x * spw + ls;
+  if (scen >= n_scen) scen = n_scen - 1;
+  const int64_t rows = n_scen * N;
+  const int64_t row = scen * N + li;
+  PandaState<T> R;
+  load_state(rows, row, q, qd, R);
+  PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+    xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+    xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+  }
+  __syncthreads();
+  T qdd[7], act[7];
+  panda_solve_row<LS>(
+      cfg, cfg.mount[li], R, P,
+      [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#pragma unroll 1
+        for (int d = 1; d < N; ++d) {
+          int jr = li + d;
+          if (jr >= N) jr -= N;
+          const int src = ls * N + jr;
+          panda_walk_spheres<LO, T>(
+              cfg, cfg.mount[jr],
+              [&](int j, T& c, T& s, T& qdj) {
+                c = xch[(3 * j + 0) * 64 + src];
+                s = xch[(3 * j + 1) * 64 + src];
+                qdj = xch[(3 * j + 2) * 64 + src];
+              },
+              [&](int s, const T* x, const T* v, const T* a) {
+                T vv[3], aa[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  vv[c] = cfg.dynamic ? v[c] : T(0);                            // EXJ:336-339
+                  aa[c] = (cfg.dynamic && use_accel) ? cfg.jsign * a[c] : T(0);  // EXJ:411 passes zeros
+                }
+                accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
+              });
+        }
+      },
+      qdd, act);
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (qdd_out) qdd_out[j * rows + row] = qdd[j];
+      act_out[j * rows + row] = act[j];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- Cartesian rollout
 template <typename T, class LS>
 __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
@@ -738,6 +809,27 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
     return launch(h, mrf::k_action_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
                   (const T*)qdot, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov,
                   (const T*)oa, (const T*)orad, (T*)qddot_out, (T*)action_out);
+  });
+}
+
+int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scen, const void* q, const void* qdot, const void* params,
+                               int32_t use_accel, void* qddot_out, void* action_out, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "coupled compute_action is defined for the panda7 model only");
+  if (h->cfg.n_robots > 64) return fail(h, MRF_E_CONFIG, "n_robots > 64");
+  if (n_scen == 0) return MRF_OK;
+  if (n_scen < 0 || !q || !qdot || !params || !action_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int spw = 64 / h->cfg.n_robots;
+  dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using LS = decltype(cl);
+    if (is_link_origin_table(h->cfg))
+      return launch(h, mrf::k_action_coupled<T, LS, true>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+                    (const T*)q, (const T*)qdot, (const T*)params, (int)use_accel, (T*)qddot_out, (T*)action_out);
+    return launch(h, mrf::k_action_coupled<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+                  (const T*)q, (const T*)qdot, (const T*)params, (int)use_accel, (T*)qddot_out, (T*)action_out);
   });
 }
 

@@ -90,6 +90,22 @@ class FabricHandle:
         self._check(rc)
         return (act, qdd) if want_qddot else act
 
+    def compute_action_coupled(self, q, qdot, params, use_accel=False, want_qddot=False, stream=None):
+        """compute_action of every robot against the spheres of the other robots of its scenario (EXJ:394-448 on the
+        device); rows = n_scenarios * n_robots -> action [7, rows]."""
+        rows = q.shape[1]
+        N = self.cfg.n_robots
+        if rows % N:
+            raise MrfError("rows must be a multiple of n_robots")
+        act = torch.empty((self.dof, rows), dtype=self.dtype, device=self.device)
+        qdd = torch.empty_like(act) if want_qddot else None
+        rc = self.lib.mrf_compute_action_coupled(self._h, rows // N, self._arg(q, (self.dof, rows), "q"),
+                                                 self._arg(qdot, (self.dof, rows), "qdot"),
+                                                 self._arg(params, (abi.NPARAM, rows), "params"), int(bool(use_accel)),
+                                                 self._arg(qdd), self._arg(act), self._stream(stream))
+        self._check(rc)
+        return (act, qdd) if want_qddot else act
+
     def rollout(self, q0, qdot0, params, want_traj=False, stream=None):
         """Coupled joint-space rollout; rows = n_scenarios * n_robots -> avg_vel [rows] (, traj_q, traj_qdot)."""
         rows = q0.shape[1]

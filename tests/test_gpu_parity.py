@@ -278,3 +278,24 @@ def test_create_rejects_bad_config():
     z = h.tensor(np.zeros((7, 2)))
     with pytest.raises(MrfError):
         h.rollout(z, z, h.tensor(np.zeros((abi.NPARAM, 2))))
+
+
+@pytest.mark.parametrize("n_per_link,use_accel,dynamic", [(1, False, 1), (1, True, 1), (2, False, 1), (1, False, 0)])
+def test_compute_action_coupled(oracle, n_per_link, use_accel, dynamic):
+    """Device-side obstacle assembly (EXJ:394-412) == fk_spheres + host gather + compute_action, and == the oracle."""
+    N, B = 3, 45
+    cfg = config.panda_config(n_robots=N, horizon=1, dynamic=dynamic)
+    if n_per_link > 1:
+        links, offs = config.sphere_offsets_per_link(n_per_link)
+        config.set_spheres(cfg, links, offs)
+    batch = scenarios.panda_batch(cfg, B, seed=71, x_min=0.15 if n_per_link > 1 else 0.05)
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv if dynamic else None,
+                                                       sa if (dynamic and use_accel) else None)
+    _, want = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"])
+    act, qdd = h.compute_action_coupled(q, qd, prm, use_accel=use_accel, want_qddot=True)
+    assert relerr(act.cpu().numpy(), want) < F64_RTOL
+    two_step = h.compute_action(q, qd, prm, h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad))
+    assert float((two_step - act).abs().max() / act.abs().max()) < 1e-11
