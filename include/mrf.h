@@ -104,6 +104,8 @@ typedef struct {
   mrf_leaf_fn collision_geometry, collision_finsler;
   mrf_leaf_fn plane_geometry, plane_finsler;
   mrf_leaf_fn limit_geometry, limit_finsler;
+  int32_t kernel_select; /* coupled kernels: 0 = auto by batch size, 1 = row-per-lane (throughput), 2 = one wave per scenario (latency) */
+  int32_t reserved0;
 } mrf_config;
 
 typedef struct mrf_handle mrf_handle;

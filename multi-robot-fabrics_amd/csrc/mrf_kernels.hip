@@ -320,6 +320,206 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
   }
 }
 
+// ---------------------------------------------------------------------------- cooperative (latency) kernels
+// One wave per scenario for small batches, where the row-per-lane kernels above would leave the chip empty and a
+// single lane would walk through ~13 k instructions per rollout step.  Lane = (robot i, ego point g, sphere chunk c):
+//   every lane walks its own robot's chain (redundantly, in parallel);
+//   one lane per robot stages that robot's sphere states (x, v, a) in LDS                       [LDS staging]
+//   each lane folds its ego point against its chunk of the other robots' spheres;
+//   the chunk partials are summed with xor-shuffles, the 5 points gathered with indexed shuffles   [wave shuffles]
+//   and every lane of a robot finishes the 7x7 part redundantly.
+// COOP_ROLLOUT = true is the coupled rollout (FPJ:190-249), false one coupled compute_action (EXJ:394-448).
+__host__ __device__ inline int coop_chunks(int n_robots) {
+  return 5 * n_robots * 4 <= 64 ? 4 : (5 * n_robots * 2 <= 64 ? 2 : 1);
+}
+
+template <typename T, class LS, bool LO, bool COOP_ROLLOUT>
+__global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
+                                                    const T* __restrict__ q0, const T* __restrict__ qd0,
+                                                    const T* __restrict__ prm, int use_accel, T* __restrict__ avg_out,
+                                                    T* __restrict__ traj_q, T* __restrict__ traj_qd,
+                                                    T* __restrict__ qdd_out, T* __restrict__ act_out) {
+  extern __shared__ __align__(16) unsigned char coop_lds[];
+  T* xch = reinterpret_cast<T*>(coop_lds);  // [21][64]  cos q, sin q, qdot of every lane (generic sphere tables)
+  T* sph = xch + 21 * 64;                    // [N][S][9] sphere states of the scenario
+  const DevCfg<T>& cfg = *cfgp;
+  const int N = cfg.n_robots;
+  const int S = LO ? 8 : cfg.n_spheres;
+  const int C = coop_chunks(N);
+  const int LPR = 5 * C;  // lanes per robot
+  const int lane = threadIdx.x;
+  int i = lane / LPR;
+  int rem = lane - i * LPR;
+  const bool idle = i >= N;  // tail lanes shadow robot 0 and never write
+  if (idle) {
+    i = 0;
+    rem = 1 % LPR;
+  }
+  const int g = rem / C;
+  const int c = rem - g * C;
+  const bool writer = !idle && rem == 0;
+  const int64_t scen = blockIdx.x;
+  const int64_t rows = n_scen * N;
+  const int64_t row = scen * N + i;
+
+  PandaState<T> R;
+  load_state(rows, row, q0, qd0, R);
+  const T* mount_own = cfg.mount[i];
+  PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
+  if (COOP_ROLLOUT && ((cfg.goal_mask >> i) & 1)) {
+    PandaKin<T> K0;
+    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.g0[k] = K0.p8[k] + cfg.goal_T * K0.v8[k];
+    P.own_goal = true;
+  }
+  const bool dyn = cfg.dynamic != 0;
+  const bool acc_on = dyn && (COOP_ROLLOUT || use_accel);
+  T sumsq = T(0);
+  const int H = COOP_ROLLOUT ? cfg.horizon : 1;
+#pragma unroll 1
+  for (int k = 0; k < H; ++k) {
+    if (COOP_ROLLOUT) {
+      T dq[7];
+      bool small = true;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        dq[j] = cfg.dt * R.qd[j];
+        small = small && (m_abs(dq[j]) < T(0.125));
+        R.q[j] += dq[j];
+      }
+      if (__all(small)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          T sd, cd;
+          small_sincos(dq[j], sd, cd);
+          const T cc = R.cq[j] * cd - R.sq[j] * sd;
+          const T ss = R.sq[j] * cd + R.cq[j] * sd;
+          R.cq[j] = cc;
+          R.sq[j] = ss;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+      }
+    }
+    PandaKin<T> K;
+    panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
+    __syncthreads();  // the previous step's readers are done with sph / xch
+    if (LO) {
+      if (writer) {
+        T* dst = sph + (size_t)i * 8 * 9;
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+#pragma unroll
+          for (int k3 = 0; k3 < 3; ++k3) {
+            const T x = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
+            const T v = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
+            const T a = sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3];
+            dst[sp * 9 + k3] = x;
+            dst[sp * 9 + 3 + k3] = dyn ? v : T(0);
+            dst[sp * 9 + 6 + k3] = acc_on ? cfg.jsign * a : T(0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+        xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+        xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+      }
+      __syncthreads();
+      panda_walk_spheres<false, T>(
+          cfg, mount_own,
+          [&](int j, T& cj, T& sj, T& qdj) {
+            cj = xch[(3 * j + 0) * 64 + lane];
+            sj = xch[(3 * j + 1) * 64 + lane];
+            qdj = xch[(3 * j + 2) * 64 + lane];
+          },
+          [&](int sp, const T* x, const T* v, const T* a) {
+            if (!writer) return;
+            T* dst = sph + ((size_t)i * S + sp) * 9;
+#pragma unroll
+            for (int k3 = 0; k3 < 3; ++k3) {
+              dst[k3] = x[k3];
+              dst[3 + k3] = dyn ? v[k3] : T(0);
+              dst[6 + k3] = acc_on ? cfg.jsign * a[k3] : T(0);
+            }
+          });
+    }
+    __syncthreads();
+
+    // ---- my ego point against my chunk of the other robots' spheres
+    EgoPts<T, 1> E1;
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      E1.p[0][k3] = g == 0 ? K.o[2][k3] : (g == 1 ? K.o[3][k3] : (g == 2 ? K.o[4][k3] : (g == 3 ? K.o[6][k3] : K.p8[k3])));
+      E1.v[0][k3] = g == 0 ? K.vo[2][k3] : (g == 1 ? K.vo[3][k3] : (g == 2 ? K.vo[4][k3] : (g == 3 ? K.vo[6][k3] : K.v8[k3])));
+    }
+    E1.rb[0][0] = P[MRF_P_RADIUS_BODY + (g < 3 ? g : g + 1)];
+    E1.rb[0][1] = P[MRF_P_RADIUS_BODY + 3];
+    E1.nl[0] = g == 2 ? 2 : 1;
+    EgoAcc<T, 1> a1;
+    a1.zero();
+    if (cfg.n_ego > 0) {
+      const int M = (N - 1) * S;
+#pragma unroll 1
+      for (int m = c; m < M; m += C) {
+        const int d = m / S;
+        const int sp = m - d * S;
+        int jr = i + 1 + d;
+        if (jr >= N) jr -= N;
+        const T* src = sph + ((size_t)jr * S + sp) * 9;
+        T x[3] = {src[0], src[1], src[2]}, v[3] = {src[3], src[4], src[5]}, a[3] = {src[6], src[7], src[8]};
+        accumulate_obstacle<typename LS::Collision>(cfg, E1, x, v, a, cfg.sphere_r[sp], false, a1);
+      }
+    }
+    // ---- sum the chunk partials, then give every lane of the robot all 5 points
+    for (int off = 1; off < C; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) a1.A[0][e] += __shfl_xor(a1.A[0][e], off);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) a1.b[0][e] += __shfl_xor(a1.b[0][e], off);
+    }
+    EgoAcc<T, NG> acc;
+#pragma unroll
+    for (int gg = 0; gg < NG; ++gg) {
+      const int srcl = i * LPR + gg * C;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) acc.A[gg][e] = __shfl(a1.A[0][e], srcl);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) acc.b[gg][e] = __shfl(a1.b[0][e], srcl);
+    }
+    EgoPts<T, NG> E;
+    panda_ego_points(K, P, E);
+    T qdd[7], act[7];
+    panda_finish_row<LS>(cfg, R, P, K, E, acc, qdd, act);
+    if (COOP_ROLLOUT) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        R.qd[j] = act[j];
+        sumsq += act[j] * act[j];
+      }
+      if (writer && traj_q) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) traj_q[((int64_t)k * 7 + j) * rows + row] = R.q[j];
+      }
+      if (writer && traj_qd) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) traj_qd[((int64_t)k * 7 + j) * rows + row] = R.qd[j];
+      }
+    } else if (writer) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (qdd_out) qdd_out[j * rows + row] = qdd[j];
+        act_out[j * rows + row] = act[j];
+      }
+    }
+  }
+  if (COOP_ROLLOUT && writer) avg_out[row] = sumsq / (T)(H * 7);
+}
+
 // ---------------------------------------------------------------------------- Cartesian rollout
 template <typename T, class LS>
 __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
@@ -515,6 +715,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
 struct mrf_handle {
   mrf_config cfg;
   int device;
+  int64_t coop_max_scen;  // batches up to this size use the cooperative kernels (auto mode)
   void* dcfg;  // DevCfg<double> or DevCfg<float> on the device
   std::string err;
 };
@@ -609,6 +810,7 @@ std::string validate(const mrf_config& c) {
   if (c.model == MRF_MODEL_PANDA7 && (c.n_goals < 0 || c.n_goals > 3)) return "panda n_goals must be 0..3";
   if (c.model == MRF_MODEL_PLANAR3 && (c.n_goals < 0 || c.n_goals > 1)) return "planar3 n_goals must be 0..1";
   if (c.obst_dim != 2 && c.obst_dim != 3) return "obst_dim must be 2 or 3";
+  if (c.kernel_select < 0 || c.kernel_select > 2) return "kernel_select must be 0 (auto), 1 (row-per-lane) or 2 (cooperative)";
   if (!(c.dt > 0) || !(c.eps > 0)) return "dt and eps must be positive";
   int prev = 0;
   for (int s = 0; s < c.n_spheres; ++s) {
@@ -661,6 +863,15 @@ bool is_link_origin_table(const mrf_config& c) {
   return true;
 }
 
+// Cooperative (one wave per scenario) kernels pay ~5x the total work of the row-per-lane kernels but finish a
+// scenario ~4x sooner; they win while the row-per-lane grid cannot fill the chip.  cfg.kernel_select overrides.
+bool use_coop(const mrf_handle* h, int64_t n_scen) {
+  if (5 * h->cfg.n_robots > 64) return false;
+  if (h->cfg.kernel_select == 1) return false;
+  if (h->cfg.kernel_select == 2) return true;
+  return n_scen <= h->coop_max_scen;
+}
+
 template <typename F>
 int dispatch_scalar(mrf_handle* h, F f) {
   return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
@@ -670,6 +881,23 @@ int dispatch(mrf_handle* h, F f) {
   const bool fast = is_panda_leafset(h->cfg);
   if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafSetPanda{}) : f(double{}, LeafSetGeneric{});
   return fast ? f(float{}, LeafSetPanda{}) : f(float{}, LeafSetGeneric{});
+}
+
+template <bool ROLLOUT>
+int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, const void* prm, int use_accel, void* avg,
+                void* traj_q, void* traj_qd, void* qdd_out, void* act_out, hipStream_t st) {
+  const bool lo = is_link_origin_table(h->cfg);
+  const int S = lo ? 8 : h->cfg.n_spheres;
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using LS = decltype(cl);
+    const size_t lds = sizeof(T) * (21 * 64 + (size_t)h->cfg.n_robots * S * 9);
+    dim3 block(64), grid((unsigned)n_scen);
+    auto k = lo ? mrf::k_coop_panda<T, LS, true, ROLLOUT> : mrf::k_coop_panda<T, LS, false, ROLLOUT>;
+    hipLaunchKernelGGL(k, grid, block, lds, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q, (const T*)qd,
+                       (const T*)prm, use_accel, (T*)avg, (T*)traj_q, (T*)traj_qd, (T*)qdd_out, (T*)act_out);
+    return check_hip(h, hipGetLastError(), "kernel launch");
+  });
 }
 
 }  // namespace
@@ -771,6 +999,11 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
     if (e == hipSuccess) e = hipMemcpy(h->dcfg, &d, sizeof(d), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) return fail(h, MRF_E_DEVICE, std::string("config upload: ") + hipGetErrorString(e));
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
+  // measured crossover (tools/crossover.py, 3-Panda H=30): 0.36 ms up to one round of 4 waves per CU, 0.84 ms at two
+  // rounds, against a flat 0.71 ms of the row-per-lane kernel -> cooperative up to 1.5 rounds
+  h->coop_max_scen = (int64_t)cus * 6;
   return MRF_OK;
 }
 
@@ -820,6 +1053,8 @@ int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scen, const void* q, con
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q || !qdot || !params || !action_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
+  if (use_coop(h, n_scen))
+    return launch_coop<false>(h, n_scen, q, qdot, params, (int)use_accel, nullptr, nullptr, nullptr, qddot_out, action_out, st);
   const int spw = 64 / h->cfg.n_robots;
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
   return dispatch(h, [&](auto t, auto cl) {
@@ -843,6 +1078,8 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
+  if (use_coop(h, n_scen))
+    return launch_coop<true>(h, n_scen, q0, qdot0, params, 1, avg_out, traj_q, traj_qd, nullptr, nullptr, st);
   const int spw = 64 / h->cfg.n_robots;
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
   return dispatch(h, [&](auto t, auto cl) {

@@ -128,6 +128,7 @@ def test_compute_action_planar(oracle, obst_dim):
     assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
 
 
+@pytest.mark.parametrize("kernel", [1, 2])        # 1 = row-per-lane (throughput), 2 = one wave per scenario (latency)
 @pytest.mark.parametrize("scalar", [abi.F64, abi.F32])
 @pytest.mark.parametrize("n_robots,horizon,n_scen,mask,dynamic", [
     (2, 20, 37, 0, 1),        # BASELINE config 3: 2-Panda RF H=20
@@ -135,9 +136,10 @@ def test_compute_action_planar(oracle, obst_dim):
     (3, 6, 22, 0, 0),         # static fabrics: exchanged v, a zeroed (FPJ:215-217); 22 scenarios -> ragged last wave
     (1, 5, 70, 0, 1),         # a single robot: no obstacles at all
 ])
-def test_rollout_jointspace(oracle, scalar, n_robots, horizon, n_scen, mask, dynamic):
+def test_rollout_jointspace(oracle, scalar, n_robots, horizon, n_scen, mask, dynamic, kernel):
     cfg = _with_scalar(config.panda_config(n_robots=n_robots, horizon=horizon, dynamic=dynamic), scalar)
     cfg.goal_estimate_mask = mask
+    cfg.kernel_select = kernel
     batch = scenarios.panda_batch(cfg, n_scen, seed=21, x_min=0.08)
     want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
     h = FabricHandle(cfg, 0)
@@ -156,9 +158,11 @@ def test_rollout_jointspace(oracle, scalar, n_robots, horizon, n_scen, mask, dyn
         assert np.allclose(avg, want_avg, rtol=1e-3, atol=1e-5)
 
 
-def test_rollout_eight_pandas(oracle):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_rollout_eight_pandas(oracle, kernel):
     """BASELINE config 5 shape: 8 Pandas on the build-defined ring, 20 spheres per robot with link-local offsets."""
     cfg = config.panda_config(n_robots=8, horizon=4)
+    cfg.kernel_select = kernel
     links, offs = config.sphere_offsets_per_link(3)
     keep = [i for i in range(len(links))][:20]
     config.set_spheres(cfg, [links[i] for i in keep], [offs[i] for i in keep])
@@ -264,6 +268,11 @@ def test_properties_at_bench_size():
     act_s = h.compute_action(q1, qd, prm, ox, None, None, orad)
     assert float((act_s - tqd_s[0]).abs().max() / tqd_s[0].abs().max()) < 1e-10
     assert np.isfinite(act.cpu().numpy()).all()
+    # the cooperative (latency) and row-per-lane (throughput) kernels agree on the whole batch
+    c1, c2 = config.panda_config(n_robots=N, horizon=5), config.panda_config(n_robots=N, horizon=5)
+    c1.kernel_select, c2.kernel_select = 1, 2
+    r1, r2 = FabricHandle(c1, 0).rollout(q, qd, prm), FabricHandle(c2, 0).rollout(q, qd, prm)
+    assert float((r1 - r2).abs().max() / r1.abs().max()) < 1e-10
 
 
 def test_create_rejects_bad_config():
@@ -280,11 +289,13 @@ def test_create_rejects_bad_config():
         h.rollout(z, z, h.tensor(np.zeros((abi.NPARAM, 2))))
 
 
+@pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("n_per_link,use_accel,dynamic", [(1, False, 1), (1, True, 1), (2, False, 1), (1, False, 0)])
-def test_compute_action_coupled(oracle, n_per_link, use_accel, dynamic):
+def test_compute_action_coupled(oracle, n_per_link, use_accel, dynamic, kernel):
     """Device-side obstacle assembly (EXJ:394-412) == fk_spheres + host gather + compute_action, and == the oracle."""
     N, B = 3, 45
     cfg = config.panda_config(n_robots=N, horizon=1, dynamic=dynamic)
+    cfg.kernel_select = kernel
     if n_per_link > 1:
         links, offs = config.sphere_offsets_per_link(n_per_link)
         config.set_spheres(cfg, links, offs)
@@ -299,3 +310,37 @@ def test_compute_action_coupled(oracle, n_per_link, use_accel, dynamic):
     assert relerr(act.cpu().numpy(), want) < F64_RTOL
     two_step = h.compute_action(q, qd, prm, h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad))
     assert float((two_step - act).abs().max() / act.abs().max()) < 1e-11
+
+
+def test_baseline_config_2_mrdf_two_pandas_ten_spheres(oracle):
+    """BASELINE configs[1]: 2-Panda MRDF joint-space (no rollout), ~10 collision spheres per robot."""
+    cfg = config.panda_config(n_robots=2, horizon=1)
+    links, offs = config.sphere_offsets_per_link(2)          # 16 candidates; keep 10 spread over links 2..8
+    keep = [2, 3, 4, 6, 8, 9, 10, 12, 14, 15]
+    config.set_spheres(cfg, [links[i] for i in keep], [offs[i] for i in keep])
+    batch = scenarios.panda_batch(cfg, 300, seed=81, x_min=0.15)
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, None)
+    assert ox.shape[0] == 10
+    want_qdd, want = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    h = FabricHandle(cfg, 0)
+    act, qdd = h.compute_action_coupled(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]),
+                                        want_qddot=True)
+    assert relerr(act.cpu().numpy(), want) < F64_RTOL and relerr(qdd.cpu().numpy(), want_qdd) < F64_RTOL
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_baseline_config_5_eight_pandas_h50(oracle, kernel):
+    """BASELINE configs[4] at its full shape: 8 Pandas, RF-CV, H=50, 20 spheres per robot (140 obstacle spheres each)."""
+    cfg = config.panda_config(n_robots=8, horizon=50)
+    cfg.kernel_select = kernel
+    links, offs = config.sphere_offsets_per_link(3)
+    config.set_spheres(cfg, links[:20], offs[:20])
+    cfg.goal_estimate_mask = 0xFE
+    batch = scenarios.panda_batch(cfg, 10, seed=91, x_min=0.3, q_spread=0.15)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    avg, tq, tqd = h.rollout(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), want_traj=True)
+    assert relerr(tq.cpu().numpy(), want_q) < F64_RTOL
+    assert relerr(tqd.cpu().numpy(), want_qd) < 1e-8       # 50 coupled steps of 8 robots: round-off compounds
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Rollout-kernel timing for the BASELINE.json configurations other than the bench workload (kernel only)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.runtime import FabricHandle
+
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+for name, N, H, S20, rounds in (("C3 2-Panda RF H=20", 2, 20, False, 6), ("C4 3-Panda RF-CV H=30", 3, 30, False, 6),
+                                ("C5 8-Panda RF-CV H=50 S=20", 8, 50, True, 2)):
+    for dtype in ("f64", "f32"):
+        cfg = config.panda_config(n_robots=N, horizon=H, scalar=abi.F64 if dtype == "f64" else abi.F32)
+        if S20:
+            links, offs = config.sphere_offsets_per_link(3)
+            config.set_spheres(cfg, links[:20], offs[:20])
+        cfg.goal_estimate_mask = ((1 << N) - 2) if "CV" in name else 0
+        B = rounds * cus * 4 * (64 // N)
+        b = scenarios.panda_batch(cfg, B, seed=5, x_min=0.3 if N == 8 else 0.05, q_spread=0.15 if N == 8 else 0.3)
+        h = FabricHandle(cfg, 0)
+        q, qd, prm = (h.tensor(b[k]) for k in ("q", "qdot", "params"))
+        h.rollout(q, qd, prm); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            h.rollout(q, qd, prm)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        sb = 8 if dtype == "f64" else 4
+        S = cfg.n_spheres
+        bytes_unit = sb * (28 + 9 * S * N) + sb * 23 / H
+        print(f"{name:28s} {dtype} B={B:7d}: {dt*1e3:8.2f} ms  {B*N*H/dt:.3e} rollout-steps/s  {B/dt:.3e} rollouts/s  "
+              f"algorithmic {B*N*H*bytes_unit/dt/1e9:7.0f} GB/s (frac {B*N*H*bytes_unit/dt/8e12:.3f})")
