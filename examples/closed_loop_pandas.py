@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Simulator-free closed loop of the N-Panda example (the planner side of examples/example_pandas_Jointspace.py:280-458):
+every control step  [Rollout Fabrics -> avg velocity]  +  compute_action for all robots against each other's collision
+spheres, then the joint velocity command is applied exactly (q += dt * clip(action)), as urdfenvs does in 'vel' mode.
+
+Runs B independent scenarios at once on the GPU and reports behavioural statistics: how many end-effectors reach
+their goal, the minimum sphere clearance between robots, joint-limit margins.  This is a plausibility check of the
+fabric specification, not a parity test.
+
+usage: python examples/closed_loop_pandas.py [--robots 2] [--scenarios 256] [--steps 1000] [--rollouts]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.runtime import FabricHandle
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--robots", type=int, default=2)
+    ap.add_argument("--scenarios", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--rollouts", action="store_true", help="also run the Rollout Fabrics every step (avg-velocity monitor)")
+    ap.add_argument("--n-obst-per-link", type=int, default=1)
+    args = ap.parse_args()
+    N, B = args.robots, args.scenarios
+    cfg = config.panda_config(n_robots=N, horizon=args.horizon)
+    if args.n_obst_per_link > 1:
+        links, offs = config.sphere_offsets_per_link(args.n_obst_per_link)
+        config.set_spheres(cfg, links, offs)
+    batch = scenarios.panda_batch(cfg, B, seed=0, qd_spread=0.0)
+    h = FabricHandle(cfg, 0)
+    roll = None
+    if args.rollouts:
+        cr = config.panda_config(n_robots=N, horizon=args.horizon)
+        roll = FabricHandle(cr, 0)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    vlim = h.tensor(np.array(config.PANDA_VEL_LIMITS)[:, None])
+    lim = h.tensor(np.array(config.PANDA_LIMITS))
+    goal = prm[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3]                       # [3, rows]
+    S = cfg.n_spheres
+    rad = h.tensor(np.array(cfg.sphere_radius[:S]))
+    min_clear = torch.full((B,), 1e9, dtype=h.dtype, device="cuda")
+    min_limit = torch.full((B * N,), 1e9, dtype=h.dtype, device="cuda")
+    reached_at = torch.full((B * N,), -1, dtype=torch.int64, device="cuda")
+    avg_hist = []
+    hard_stops = 0
+    for t in range(args.steps):
+        if roll is not None:
+            avg_hist.append(float(roll.rollout(q, qd, prm).mean()))
+        act = h.compute_action_coupled(q, qd, prm, use_accel=False)
+        act = torch.minimum(torch.maximum(act, -vlim), vlim)           # EXJ:288,453
+        q = q + cfg.dt * act
+        # pybullet enforces the URDF joint limits as hard stops; the explicit Euler step here can jump the soft barrier
+        # of the limit leaves (0.02 rad per step at full speed), so the stop is emulated just inside the limit
+        stop = torch.minimum(torch.maximum(q, lim[:, 0:1] + 1e-3), lim[:, 1:2] - 1e-3)
+        hard_stops += int((stop != q).sum())
+        q = stop.contiguous()
+        qd = act.contiguous()
+        if t % 10 == 0 or t == args.steps - 1:
+            x, _, _ = h.fk_spheres(q)                                  # [S,3,rows]
+            xs = x.view(S, 3, B, N)
+            for i in range(N):
+                for j in range(i + 1, N):
+                    d = (xs[:, None, :, :, i] - xs[None, :, :, :, j]).norm(dim=2)          # [S,S,B]
+                    clear = d - rad[:, None, None] - rad[None, :, None]
+                    min_clear = torch.minimum(min_clear, clear.reshape(S * S, B).min(0).values)
+            ee = x[max(s for s in range(S) if cfg.sphere_link[s] == 8)]                     # a sphere on link 8
+            if all(cfg.sphere_offset[s][k] == 0.0 for s in range(S) for k in range(3)):
+                dist = (ee - goal).norm(dim=0)
+                newly = (dist < 0.05) & (reached_at < 0)
+                reached_at[newly] = t
+            margin = torch.minimum(q - lim[:, 0:1], lim[:, 1:2] - q).min(0).values
+            min_limit = torch.minimum(min_limit, margin)
+    torch.cuda.synchronize()
+    out = {
+        "robots": N, "scenarios": B, "steps": args.steps, "dt": cfg.dt, "spheres_per_robot": S,
+        "all_finite": bool(torch.isfinite(q).all()),
+        "goal_reached_fraction": float((reached_at >= 0).double().mean()),
+        "median_steps_to_goal": float(reached_at[reached_at >= 0].double().median()) if (reached_at >= 0).any() else None,
+        "final_ee_goal_distance_mean": float((h.fk_spheres(q)[0][S - 1] - goal).norm(dim=0).mean()),
+        "min_sphere_clearance_m": float(min_clear.min()), "scenarios_with_contact": int((min_clear < 0).sum()),
+        "min_joint_limit_margin_rad": float(min_limit.min()), "joint_hard_stop_events": hard_stops,
+        "final_speed_mean": float(qd.norm(dim=0).mean()),
+    }
+    if avg_hist:
+        out["rollout_avg_velocity_first_last"] = [avg_hist[0], avg_hist[-1]]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
