@@ -291,9 +291,10 @@ class ParameterizedFabricPlanner:
         prm = self.params_row(kwargs)
         ox, ov, oa, orad, ns = self.obstacle_arrays(kwargs)
         M = ox.shape[0]
-        args = [h.tensor(q[:, None]), h.tensor(qd[:, None]), h.tensor(prm[:, None])]
         if M:
-            args += [h.tensor(ox[:, :, None]), h.tensor(ov[:, :, None]), h.tensor(oa[:, :, None]), h.tensor(orad[:, None])]
+            args = h.upload(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None], oa[:, :, None], orad[:, None])
+        else:
+            args = h.upload(q[:, None], qd[:, None], prm[:, None])
         act = h.compute_action(*args, n_static=ns)
         return act[:, 0].cpu().numpy().astype(np.float64)
 

@@ -119,8 +119,8 @@ class ForwardFabricsPlanner:
         if self._handle is None:
             raise RuntimeError("call forward_multi_fabrics_symbolic() first")
         h = self._handle
-        q, qd, prm = self._rows(inputs_action)
-        return h.rollout(h.tensor(q), h.tensor(qd), h.tensor(prm), want_traj=traj)
+        q, qd, prm = h.upload(*self._rows(inputs_action))
+        return h.rollout(q, qd, prm, want_traj=traj)
 
     # -- the reference's entry points --------------------------------------------------------------------------------
     def get_velocity_rollouts(self, inputs_action):
@@ -288,13 +288,13 @@ class FabricsRollouts:
             raise RuntimeError("call symbolic_forward_fabrics() first")
         h = self._handle
         q, qd, prm, ox, ov, oa, orad = self._unpack(arguments)
-        t = h.tensor
         if ox.shape[0]:
-            obst = (t(ox[:, :, None]), t(ov[:, :, None]), t(oa[:, :, None]), t(orad[:, None]))
+            qt, qdt, pt, *obst = h.upload(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None],
+                                          oa[:, :, None], orad[:, None])
         else:
+            qt, qdt, pt = h.upload(q[:, None], qd[:, None], prm[:, None])
             obst = (None, None, None, None)
-        return h.rollout_cartesian(t(q[:, None]), t(qd[:, None]), t(prm[:, None]), *obst, want_traj=traj,
-                                   n_static=self.nr_obsts)
+        return h.rollout_cartesian(qt, qdt, pt, *obst, want_traj=traj, n_static=self.nr_obsts)
 
     def get_velocity_rollouts(self, arguments):
         """-> DM-like array of shape (1,) whose .full() is (1,1), as `avg_vel_fun(*arguments)` (FPC:561-563)."""

@@ -59,6 +59,21 @@ class FabricHandle:
         """Host/any array -> contiguous device tensor of the handle's scalar type."""
         return torch.as_tensor(a, dtype=self.dtype).to(self.device).contiguous()
 
+    def upload(self, *arrays):
+        """Several host arrays -> device tensors of the handle's scalar type with ONE host-to-device copy
+        (the single-row planner calls are latency-bound by the number of transfers, not by their size)."""
+        import numpy as np
+        np_dtype = np.float64 if self.dtype == torch.float64 else np.float32
+        arrs = [np.ascontiguousarray(a, dtype=np_dtype) for a in arrays]
+        sizes = [a.size for a in arrs]
+        flat = np.concatenate([a.reshape(-1) for a in arrs]) if arrs else np.zeros(0, dtype=np_dtype)
+        dev = torch.from_numpy(flat).to(self.device)
+        out, off = [], 0
+        for a, n in zip(arrs, sizes):
+            out.append(dev[off:off + n].view(a.shape))
+            off += n
+        return out
+
     def _arg(self, t, shape=None, name="tensor"):
         if t is None:
             return None
