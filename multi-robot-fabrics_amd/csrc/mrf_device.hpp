@@ -840,14 +840,21 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
 // walked twice: once for the ego points the obstacle loop needs (positions, velocities), once afterwards for the
 // joint axes / origins / curvature terms of the pullback -- recomputing ~300 flops is cheaper than keeping
 // ~60 more values live across the loop (register pressure is what limits these kernels).
-template <class LS, typename T, class PRM, class Obst>
+struct NoPublish {
+  template <typename K>
+  __device__ __forceinline__ void operator()(const K&) const {}
+};
+
+template <class LS, typename T, class PRM, class Obst, class Publish = NoPublish>
 __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* __restrict__ mount, const PandaState<T>& R,
-                                                const PRM& prm, Obst obstacles, T (&qdd)[7], T (&act)[7]) {
+                                                const PRM& prm, Obst obstacles, T (&qdd)[7], T (&act)[7],
+                                                Publish publish = Publish()) {
   EgoPts<T, NG> E;
   {
     PandaKin<T> K1;
     panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K1);
     panda_ego_points(K1, prm, E);
+    publish(K1);  // coupled kernels: hand this robot's link states to the other lanes of the scenario
   }
   EgoAcc<T, NG> acc;
   acc.zero();

@@ -129,6 +129,42 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
   }
 }
 
+// Link-origin sphere table (the reference's rollouts, PM:25-26): every lane already has its own robot's link
+// origins, velocities and Jdot*qdot from its own chain walk, so it stages them once in a per-wave LDS tile
+// [72][64] (8 links x (x, v, a)) and reads the other robots' entries from there -- no lane re-walks another
+// robot's chain.  4 resident waves x 36.9 KB (f64) fit the CU's 160 KB.
+template <typename T>
+__device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int lane, const PandaKin<T>& K, bool dyn,
+                                                      bool acc_on, T jsign) {
+#pragma unroll
+  for (int sp = 0; sp < 8; ++sp) {
+#pragma unroll
+    for (int k3 = 0; k3 < 3; ++k3) {
+      const T x = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
+      const T v = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
+      const T a = sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3];
+      tile[(sp * 9 + k3) * 64 + lane] = x;
+      tile[(sp * 9 + 3 + k3) * 64 + lane] = dyn ? v : T(0);
+      tile[(sp * 9 + 6 + k3) * 64 + lane] = acc_on ? jsign * a : T(0);
+    }
+  }
+}
+
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const T* __restrict__ tile, int ls, int li, int N,
+                                                    const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  const int M = (N - 1) * 8;
+#pragma unroll 1
+  for (int m = 0; m < M; ++m) {
+    const int d = m >> 3, sp = m & 7;
+    int jr = li + 1 + d;
+    if (jr >= N) jr -= N;
+    const T* src = tile + (sp * 9) * 64 + ls * N + jr;
+    T x[3] = {src[0], src[64], src[128]}, v[3] = {src[192], src[256], src[320]}, a[3] = {src[384], src[448], src[512]};
+    accumulate_obstacle<CL>(cfg, E, x, v, a, cfg.sphere_r[sp], false, acc);
+  }
+}
+
 // ---------------------------------------------------------------------------- coupled joint-space rollout
 // One wave per block.  Lanes are (scenario, robot) pairs with the N robots of a scenario adjacent, so the
 // exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
@@ -139,7 +175,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
                                                        T* __restrict__ traj_q, T* __restrict__ traj_qd) {
-  __shared__ T xch[21 * 64];
+  __shared__ T xch[(LO ? 72 : 21) * 64];
   const DevCfg<T>& cfg = *cfgp;
   const int N = cfg.n_robots;
   const int spw = 64 / N;  // scenarios per wave
@@ -196,42 +232,56 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
 #pragma unroll
       for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      xch[(3 * j + 0) * 64 + lane] = R.cq[j];
-      xch[(3 * j + 1) * 64 + lane] = R.sq[j];
-      xch[(3 * j + 2) * 64 + lane] = R.qd[j];
-    }
-    __syncthreads();
     T qdd[7], act[7];
-    panda_solve_row<LS>(
-        cfg, mount_own, R, P,
-        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-#pragma unroll 1
-          for (int d = 1; d < N; ++d) {
-            int jr = li + d;
-            if (jr >= N) jr -= N;
-            const int src = ls * N + jr;
-            panda_walk_spheres<LO, T>(
-                cfg, cfg.mount[jr],
-                [&](int j, T& c, T& s, T& qdj) {
-                  c = xch[(3 * j + 0) * 64 + src];
-                  s = xch[(3 * j + 1) * 64 + src];
-                  qdj = xch[(3 * j + 2) * 64 + src];
-                },
-                [&](int s, const T* x, const T* v, const T* a) {
-                  T vv[3], aa[3];
+    if constexpr (LO) {
+      panda_solve_row<LS>(
+          cfg, mount_own, R, P,
+          [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+            obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
+          },
+          qdd, act,
+          [&](const PandaKin<T>& K1) {
+            __syncthreads();
+            publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0, cfg.jsign);  // FPJ:97-99,215-220
+            __syncthreads();
+          });
+    } else {
+      __syncthreads();
 #pragma unroll
-                  for (int c = 0; c < 3; ++c) {
-                    vv[c] = cfg.dynamic ? v[c] : T(0);              // FPJ:215-220
-                    aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);  // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
-                  }
-                  accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
-                });
-          }
-        },
-        qdd, act);
+      for (int j = 0; j < 7; ++j) {
+        xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+        xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+        xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+      }
+      __syncthreads();
+      panda_solve_row<LS>(
+          cfg, mount_own, R, P,
+          [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#pragma unroll 1
+            for (int d = 1; d < N; ++d) {
+              int jr = li + d;
+              if (jr >= N) jr -= N;
+              const int src = ls * N + jr;
+              panda_walk_spheres<false, T>(
+                  cfg, cfg.mount[jr],
+                  [&](int j, T& c, T& s, T& qdj) {
+                    c = xch[(3 * j + 0) * 64 + src];
+                    s = xch[(3 * j + 1) * 64 + src];
+                    qdj = xch[(3 * j + 2) * 64 + src];
+                  },
+                  [&](int s, const T* x, const T* v, const T* a) {
+                    T vv[3], aa[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                      vv[c] = cfg.dynamic ? v[c] : T(0);              // FPJ:215-220
+                      aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);  // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
+                    }
+                    accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
+                  });
+            }
+          },
+          qdd, act);
+    }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       R.qd[j] = act[j];  // FPJ:233
@@ -259,7 +309,7 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
                                                         const T* __restrict__ q, const T* __restrict__ qd,
                                                         const T* __restrict__ prm, int use_accel,
                                                         T* __restrict__ qdd_out, T* __restrict__ act_out) {
-  __shared__ T xch[21 * 64];
+  __shared__ T xch[(LO ? 72 : 21) * 64];
   const DevCfg<T>& cfg = *cfgp;
   const int N = cfg.n_robots;
   const int spw = 64 / N;
@@ -276,41 +326,54 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
   PandaState<T> R;
   load_state(rows, row, q, qd, R);
   PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    xch[(3 * j + 0) * 64 + lane] = R.cq[j];
-    xch[(3 * j + 1) * 64 + lane] = R.sq[j];
-    xch[(3 * j + 2) * 64 + lane] = R.qd[j];
-  }
-  __syncthreads();
   T qdd[7], act[7];
-  panda_solve_row<LS>(
-      cfg, cfg.mount[li], R, P,
-      [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-#pragma unroll 1
-        for (int d = 1; d < N; ++d) {
-          int jr = li + d;
-          if (jr >= N) jr -= N;
-          const int src = ls * N + jr;
-          panda_walk_spheres<LO, T>(
-              cfg, cfg.mount[jr],
-              [&](int j, T& c, T& s, T& qdj) {
-                c = xch[(3 * j + 0) * 64 + src];
-                s = xch[(3 * j + 1) * 64 + src];
-                qdj = xch[(3 * j + 2) * 64 + src];
-              },
-              [&](int s, const T* x, const T* v, const T* a) {
-                T vv[3], aa[3];
+  if constexpr (LO) {
+    panda_solve_row<LS>(
+        cfg, cfg.mount[li], R, P,
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+          obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
+        },
+        qdd, act,
+        [&](const PandaKin<T>& K1) {
+          publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0 && use_accel != 0, cfg.jsign);  // EXJ:336-339,411
+          __syncthreads();
+        });
+  } else {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  vv[c] = cfg.dynamic ? v[c] : T(0);                            // EXJ:336-339
-                  aa[c] = (cfg.dynamic && use_accel) ? cfg.jsign * a[c] : T(0);  // EXJ:411 passes zeros
-                }
-                accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
-              });
-        }
-      },
-      qdd, act);
+    for (int j = 0; j < 7; ++j) {
+      xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+      xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+      xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+    }
+    __syncthreads();
+    panda_solve_row<LS>(
+        cfg, cfg.mount[li], R, P,
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#pragma unroll 1
+          for (int d = 1; d < N; ++d) {
+            int jr = li + d;
+            if (jr >= N) jr -= N;
+            const int src = ls * N + jr;
+            panda_walk_spheres<false, T>(
+                cfg, cfg.mount[jr],
+                [&](int j, T& c, T& s, T& qdj) {
+                  c = xch[(3 * j + 0) * 64 + src];
+                  s = xch[(3 * j + 1) * 64 + src];
+                  qdj = xch[(3 * j + 2) * 64 + src];
+                },
+                [&](int s, const T* x, const T* v, const T* a) {
+                  T vv[3], aa[3];
+#pragma unroll
+                  for (int c = 0; c < 3; ++c) {
+                    vv[c] = cfg.dynamic ? v[c] : T(0);                            // EXJ:336-339
+                    aa[c] = (cfg.dynamic && use_accel) ? cfg.jsign * a[c] : T(0);  // EXJ:411 passes zeros
+                  }
+                  accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
+                });
+          }
+        },
+        qdd, act);
+  }
   if (active) {
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
