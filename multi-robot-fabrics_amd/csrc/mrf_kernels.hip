@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restric
   load_state(rows, r, q, qd, R);
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   T qdd[7], act[7];
-  panda_solve_row<LS>(
+  panda_solve_row<LS, true>(
       cfg, cfg.mount[(int)(r % cfg.n_robots)], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
         obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E, acc);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
     }
     T qdd[7], act[7];
     if constexpr (LO) {
-      panda_solve_row<LS>(
+      panda_solve_row<LS, true>(
           cfg, mount_own, R, P,
           [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
             obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
         xch[(3 * j + 2) * 64 + lane] = R.qd[j];
       }
       __syncthreads();
-      panda_solve_row<LS>(
+      panda_solve_row<LS, false>(
           cfg, mount_own, R, P,
           [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
 #pragma unroll 1
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
   PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
   T qdd[7], act[7];
   if constexpr (LO) {
-    panda_solve_row<LS>(
+    panda_solve_row<LS, true>(
         cfg, cfg.mount[li], R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
       xch[(3 * j + 2) * 64 + lane] = R.qd[j];
     }
     __syncthreads();
-    panda_solve_row<LS>(
+    panda_solve_row<LS, false>(
         cfg, cfg.mount[li], R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
 #pragma unroll 1
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __r
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
     T qdd[7], act[7];
-    panda_solve_row<LS>(
+    panda_solve_row<LS, false>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   const int N = cfg.n_robots, S = cfg.n_spheres;
   T qdd[7], act[7];
-  panda_solve_row<LS>(
+  panda_solve_row<LS, true>(
       cfg, cfg.mount[me], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
 #pragma unroll 1
