@@ -92,7 +92,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MRF_HIP_LIB") or LIB_PATH  # MRF_HIP_LIB: A/B-ing kernel builds (tools/)
     if not os.path.exists(p):
         raise MrfLibraryError(
             f"{p} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "

@@ -130,6 +130,14 @@ __device__ __forceinline__ void small_sincos(T d, T& s, T& c) {
 }
 
 // keeps the compiler from merging a recomputation with an earlier, identical one (register lifetime control)
+// -DMRF_ISA_MARKS plants comment markers in the assembly so that tools/isa_stats.py can attribute instructions
+// to phases of the solve (the markers emit no instruction)
+#ifdef MRF_ISA_MARKS
+#define MRF_MARK(name) asm volatile("; MRFMARK " name)
+#else
+#define MRF_MARK(name)
+#endif
+
 __device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void opaque(float& x) { asm volatile("" : "+v"(x)); }
 
@@ -462,9 +470,12 @@ struct LeafPow {
   static_assert(PL >= 2 && PG >= 1, "LeafPow needs PL >= 2 and PG >= 1");
 };
 
-// weights of one spherical-obstacle leaf:  wm = m/R^2,  wf = f/R   (d = distance, nv = n.v_rel, R = r_o + r_b)
+// One spherical-obstacle leaf (d = distance, nv = n.v_rel, R = r_o + r_b, curv = sign*kappa - n.a_o):
+//   wm = m/R^2   and   wf = f/R + wm*curv,   the weights of n n^T and of n in the pulled-back (A, b).
+// Compile-time leaves: with t = 1/(d - R), u = R t = 1/x and cgnv2 = kg*gate_g*nv^2 (shared by the leaves of a point)
+//   wm = (2 kl gate_l) u^(PL-2) t^2 ,   wf = wm * (u^(PG-1) t * cgnv2 + curv)
 template <class CL, typename T>
-__device__ __forceinline__ void collision_weights(const DevCfg<T>& cfg, T d, T nv, T R, T& wm, T& fR) {
+__device__ __forceinline__ void collision_leaf(const DevCfg<T>& cfg, T d, T nv, T R, T curv, T cl, T cgnv2, T& wm, T& wf) {
   if constexpr (CL::generic) {
     T iR = fast_rcp(R);
     T x = d * iR - T(1);
@@ -472,12 +483,20 @@ __device__ __forceinline__ void collision_weights(const DevCfg<T>& cfg, T d, T n
     T m, f;
     scalar_leaf(cfg.cg, cfg.cf, x, xd, m, f);
     wm = m * iR * iR;
-    fR = f * iR;
+    wf = f * iR + wm * curv;
   } else {
-    T t = fast_rcp(d - R);
-    T gl = gate_value<T>(CL::gl, nv), gg = gate_value<T>(CL::gg, nv);  // sign(xd) == sign(nv), R > 0
-    wm = T(2) * cfg.cf.k * gl * cpow<CL::pl - 2>(R) * cpow<CL::pl>(t);
-    fR = wm * (cfg.cg.k * gg) * cpow<CL::pg - 1>(R) * cpow<CL::pg>(t) * nv * nv;
+    const T t = fast_rcp(d - R);
+    const T u = R * t;
+    T ug;  // u^(PG-1) t
+    if constexpr (CL::pl == 4 && CL::pg == 4) {
+      const T ut = u * t;
+      wm = cl * (ut * ut);
+      ug = (u * u) * ut;
+    } else {
+      wm = cl * cpow<CL::pl - 2>(u) * (t * t);
+      ug = cpow<CL::pg - 1>(u) * t;
+    }
+    wf = wm * (ug * cgnv2 + curv);
   }
 }
 
@@ -498,15 +517,18 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
     T kap = (dot3(vr, vr) - nv * nv) * id;
     T na = planar ? n[0] * a_o[0] + n[1] * a_o[1] : dot3(n, a_o);
     T curv = cfg.jsign * kap - na;
-    T wM = T(0), wf = T(0);
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      if (l < E.nl[g]) {
-        T wm, fR;
-        collision_weights<CL>(cfg, d, nv, ro + E.rb[g][l], wm, fR);
-        wM += wm;
-        wf += fR + wm * curv;
-      }
+    T cl = T(0), cgnv2 = T(0);
+    if constexpr (!CL::generic) {
+      cl = T(2) * cfg.cf.k * gate_value<T>(CL::gl, nv);  // sign(xd) == sign(nv), R > 0
+      cgnv2 = cfg.cg.k * gate_value<T>(CL::gg, nv) * nv * nv;
+    }
+    T wM, wf;  // every ego point carries at least one link (nl >= 1)
+    collision_leaf<CL>(cfg, d, nv, ro + E.rb[g][0], curv, cl, cgnv2, wM, wf);
+    if (E.nl[g] > 1) {
+      T wm2, wf2;
+      collision_leaf<CL>(cfg, d, nv, ro + E.rb[g][1], curv, cl, cgnv2, wm2, wf2);
+      wM += wm2;
+      wf += wf2;
     }
     T w0 = wM * n[0], w1 = wM * n[1], w2 = wM * n[2];
     acc.A[g][0] += w0 * n[0];
@@ -597,23 +619,23 @@ __device__ __forceinline__ void pull_point(QSpec<T, 7>& S, const PandaKin<T>& K,
 // LDL^T solve of (M + eps I) h = f, M symmetric positive definite, upper-triangle storage (copy is consumed)
 template <typename T, int N>
 __device__ __forceinline__ void ldl_solve(const QSpec<T, N>& S, T eps, T (&h)[N]) {
-  T L[N * (N + 1) / 2];  // strict upper part holds L^T, diagonal holds 1/d
-#pragma unroll
-  for (int k = 0; k < N * (N + 1) / 2; ++k) L[k] = S.M[k];
+  // A = L D L^T with both L_ij and W_ij = L_ij d_j kept, so that every inner term is one fma:
+  //   d_j = A_jj - sum_k L_jk W_jk ,   W_ij = A_ij - sum_k L_ik W_jk ,   L_ij = W_ij / d_j
+  T L[N * (N + 1) / 2], W[N * (N + 1) / 2];  // entry (i, j), i > j, stored at tri(j, i)
   T dinv[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    T d = L[tri<N>(j, j)] + eps;
+    T d = S.M[tri<N>(j, j)] + eps;
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[tri<N>(k, j)] * L[tri<N>(k, j)] * L[tri<N>(k, k)];
-    L[tri<N>(j, j)] = d;       // d_j
+    for (int k = 0; k < j; ++k) d -= L[tri<N>(k, j)] * W[tri<N>(k, j)];
     dinv[j] = fast_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
-      T v = L[tri<N>(j, i)];
+      T v = S.M[tri<N>(j, i)];
 #pragma unroll
-      for (int k = 0; k < j; ++k) v -= L[tri<N>(k, i)] * L[tri<N>(k, j)] * L[tri<N>(k, k)];
-      L[tri<N>(j, i)] = v * dinv[j];  // L_ij
+      for (int k = 0; k < j; ++k) v -= L[tri<N>(k, i)] * W[tri<N>(k, j)];
+      W[tri<N>(j, i)] = v;
+      L[tri<N>(j, i)] = v * dinv[j];
     }
   }
   T y[N];
@@ -750,6 +772,7 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
               acc.b[g][2] + acc.A[g][2] * c[0] + acc.A[g][4] * c[1] + acc.A[g][5] * c[2]};     \
     pull_point<T, NC>(S, K, pp, acc.A[g], t);                                                  \
   }
+    MRF_MARK("plane");
     MRF_PULL(0, 2, K.o[jo[0]], K.ao[jo[0]])
     MRF_PULL(1, 3, K.o[jo[1]], K.ao[jo[1]])
     MRF_PULL(2, 4, K.o[jo[2]], K.ao[jo[2]])
@@ -757,6 +780,7 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
     MRF_PULL(4, 6, K.p8, K.a8)
 #undef MRF_PULL
   }
+  MRF_MARK("pull");
   if (cfg.use_limits) {
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -769,8 +793,10 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
       S.f[j] -= f;
     }
   }
+  MRF_MARK("limits");
   T hg[7], hf[7];
   ldl_solve<T, 7>(S, cfg.eps, hg);
+  MRF_MARK("ldl_geometry");
   T qq = T(0), qh = T(0);
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
@@ -790,6 +816,7 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
       T t[3] = {f0[0] + twoA * cfg.jsign * K.a8[0], f0[1] + twoA * cfg.jsign * K.a8[1], f0[2] + twoA * cfg.jsign * K.a8[2]};
       pull_point<T, 6>(S, K, K.p8, A6, t);
     }
+    MRF_MARK("attractor0");
     if (cfg.n_goals > 1) {
       // attractor 1: R (p_hand - p_link7) -> x_goal_1 ; p_hand - p_link7 = 0.107 z_6   (EXJ:42-52)
       T Rm[9];
@@ -828,12 +855,15 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
       S.M[tri<7>(6, 6)] += twoA;
       S.f[6] += f2[0];
     }
+    MRF_MARK("attractor12");
     ldl_solve<T, 7>(S, cfg.eps, hf);
+    MRF_MARK("ldl_forced");
   } else {
 #pragma unroll
     for (int j = 0; j < 7; ++j) hf[j] = hg[j];
   }
   finish<T, 7>(cfg, R.qd, forced, alpha_g, hg, hf, xpsi, qdd, act);
+  MRF_MARK("finish");
 }
 
 // One fabric solve of a Panda row.  `obstacles(E, acc)` adds the spherical-obstacle leaves.  The own chain is
@@ -854,14 +884,18 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
                                                 const PRM& prm, Obst obstacles, T (&qdd)[7], T (&act)[7],
                                                 Publish publish = Publish()) {
   if constexpr (SINGLE_WALK) {
+    MRF_MARK("integrate");
     PandaKin<T> K;
     panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K);
     EgoPts<T, NG> E;
     panda_ego_points(K, prm, E);
+    MRF_MARK("walk");
     publish(K);
     EgoAcc<T, NG> acc;
     acc.zero();
+    MRF_MARK("publish");
     if (cfg.n_ego > 0) obstacles(E, acc);
+    MRF_MARK("obstacles");
     panda_finish_row<LS>(cfg, R, prm, K, E, acc, qdd, act);
     return;
   }

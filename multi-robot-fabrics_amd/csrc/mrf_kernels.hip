@@ -150,18 +150,56 @@ __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int l
   }
 }
 
+constexpr int TILE_RADII = 72 * 64;  // the 8 link-sphere radii follow the [72][64] tile
+constexpr int TILE_SCALARS = TILE_RADII + 8;
+
+template <typename T>
+__device__ __forceinline__ void stage_sphere_radii(const DevCfg<T>& cfg, T* __restrict__ tile, int lane) {
+  if (lane < 8) tile[TILE_RADII + lane] = cfg.sphere_r[lane];
+}
+
 template <class CL, typename T>
 __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const T* __restrict__ tile, int ls, int li, int N,
                                                     const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  // One wave per SIMD: nothing else hides the LDS / scalar-load latency, so the next sphere's nine scalars and
+  // radius are fetched before the current sphere's leaves are evaluated (software pipeline, depth 1).
   const int M = (N - 1) * 8;
-#pragma unroll 1
-  for (int m = 0; m < M; ++m) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  typedef const volatile __attribute__((address_space(3))) T* lds_vptr;
+  auto address = [&](int m) {
     const int d = m >> 3, sp = m & 7;
     int jr = li + 1 + d;
     if (jr >= N) jr -= N;
-    const T* src = tile + (sp * 9) * 64 + ls * N + jr;
-    T x[3] = {src[0], src[64], src[128]}, v[3] = {src[192], src[256], src[320]}, a[3] = {src[384], src[448], src[512]};
-    accumulate_obstacle<CL>(cfg, E, x, v, a, cfg.sphere_r[sp], false, acc);
+    return (sp * 9) * 64 + ls * N + jr;
+  };
+  T nxt[9], rnxt;
+  {
+    // The first fetch is volatile so that the optimizer cannot merge it with the in-loop fetch into one load of
+    // a loop-carried address at the top of the loop (which would undo the pipeline).
+    lds_vptr src = (lds_vptr)(tile + address(0));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) nxt[k] = src[k * 64];
+    rnxt = ((lds_vptr)tile)[TILE_RADII];
+  }
+  if constexpr (!CL::generic) {
+    // Have the scalar loads of the leaf constants complete before the loop: the wait-count pass is static, so a
+    // scalar load still pending at loop entry would put an lgkmcnt(0) -- and with it a wait for the prefetch
+    // just issued -- into every iteration.
+    asm volatile("" ::"s"(cfg.jsign), "s"(cfg.cf.k), "s"(cfg.cg.k));
+  }
+#pragma unroll 1
+  for (int m = 0; m < M; ++m) {
+    T cur[9], rcur = rnxt;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
+    {
+      const int mn = m + 1 < M ? m + 1 : m;
+      lds_ptr src = (lds_ptr)(tile + address(mn));
+#pragma unroll
+      for (int k = 0; k < 9; ++k) nxt[k] = src[k * 64];
+      rnxt = ((lds_ptr)tile)[TILE_RADII + (mn & 7)];  // staged once per kernel by stage_sphere_radii
+    }
+    accumulate_obstacle<CL>(cfg, E, cur, cur + 3, cur + 6, rcur, false, acc);
   }
 }
 
@@ -175,8 +213,9 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
                                                        T* __restrict__ traj_q, T* __restrict__ traj_qd) {
-  __shared__ T xch[(LO ? 72 : 21) * 64];
+  __shared__ T xch[LO ? TILE_SCALARS : 21 * 64];
   const DevCfg<T>& cfg = *cfgp;
+  if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
   const int spw = 64 / N;  // scenarios per wave
   const int lane = threadIdx.x;
@@ -309,8 +348,9 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
                                                         const T* __restrict__ q, const T* __restrict__ qd,
                                                         const T* __restrict__ prm, int use_accel,
                                                         T* __restrict__ qdd_out, T* __restrict__ act_out) {
-  __shared__ T xch[(LO ? 72 : 21) * 64];
+  __shared__ T xch[LO ? TILE_SCALARS : 21 * 64];
   const DevCfg<T>& cfg = *cfgp;
+  if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
   const int spw = 64 / N;
   const int lane = threadIdx.x;
