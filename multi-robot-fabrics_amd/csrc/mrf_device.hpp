@@ -616,6 +616,24 @@ __device__ __forceinline__ void pull_point(QSpec<T, 7>& S, const PandaKin<T>& K,
     for (int j = i; j < NC; ++j) S.M[tri<7>(i, j)] += dot3(J[i], AJ[j]);
 }
 
+// pull_point for an isotropic leaf metric A = a I:  M_q += a J^T J ; f_q += J^T t
+template <typename T, int NC>
+__device__ __forceinline__ void pull_point_iso(QSpec<T, 7>& S, const PandaKin<T>& K, const T* p, T a, const T* t) {
+  T J[NC][3], aJ[NC][3];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    T r[3] = {p[0] - K.o[j][0], p[1] - K.o[j][1], p[2] - K.o[j][2]};
+    cross3(K.z[j], r, J[j]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aJ[j][k] = a * J[j][k];
+    S.f[j] += dot3(J[j], t);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+#pragma unroll
+    for (int j = i; j < NC; ++j) S.M[tri<7>(i, j)] += dot3(J[i], aJ[j]);
+}
+
 // LDL^T solve of (M + eps I) h = f, M symmetric positive definite, upper-triangle storage (copy is consumed)
 template <typename T, int N>
 __device__ __forceinline__ void ldl_solve(const QSpec<T, N>& S, T eps, T (&h)[N]) {
@@ -812,9 +830,8 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
       T x0[3] = {K.p8[0] - prm[MRF_P_X_GOAL_0], K.p8[1] - prm[MRF_P_X_GOAL_0 + 1], K.p8[2] - prm[MRF_P_X_GOAL_0 + 2]};
       T twoA, f0[3];
       attractor<T, 3>(cfg, x0, prm[MRF_P_WEIGHT_GOAL_0], twoA, f0, xpsi);
-      T A6[6] = {twoA, T(0), T(0), twoA, T(0), twoA};
       T t[3] = {f0[0] + twoA * cfg.jsign * K.a8[0], f0[1] + twoA * cfg.jsign * K.a8[1], f0[2] + twoA * cfg.jsign * K.a8[2]};
-      pull_point<T, 6>(S, K, K.p8, A6, t);
+      pull_point_iso<T, 6>(S, K, K.p8, twoA, t);
     }
     MRF_MARK("attractor0");
     if (cfg.n_goals > 1) {

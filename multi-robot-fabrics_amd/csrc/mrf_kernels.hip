@@ -136,17 +136,33 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 template <typename T>
 __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int lane, const PandaKin<T>& K, bool dyn,
                                                       bool acc_on, T jsign) {
+  // dyn / acc_on are wave-uniform: branch once instead of selecting per value
 #pragma unroll
-  for (int sp = 0; sp < 8; ++sp) {
+  for (int sp = 0; sp < 8; ++sp)
 #pragma unroll
-    for (int k3 = 0; k3 < 3; ++k3) {
-      const T x = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
-      const T v = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
-      const T a = sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3];
-      tile[(sp * 9 + k3) * 64 + lane] = x;
-      tile[(sp * 9 + 3 + k3) * 64 + lane] = dyn ? v : T(0);
-      tile[(sp * 9 + 6 + k3) * 64 + lane] = acc_on ? jsign * a : T(0);
-    }
+    for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + k3) * 64 + lane] = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
+  if (dyn) {
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp)
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + 3 + k3) * 64 + lane] = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
+  } else {
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp)
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + 3 + k3) * 64 + lane] = T(0);
+  }
+  if (acc_on) {
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp)
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3)
+        tile[(sp * 9 + 6 + k3) * 64 + lane] = jsign * (sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3]);
+  } else {
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp)
+#pragma unroll
+      for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + 6 + k3) * 64 + lane] = T(0);
   }
 }
 
