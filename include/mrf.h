@@ -181,6 +181,77 @@ int mrf_step_predict(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, in
 int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
                     void* qdot_io, const void* params, const void* sph_all, void* sumsq_io, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Device-resident control step: everything between two simulator steps of
+ * examples/example_pandas_Jointspace.py:280-458 stays on the GPU,
+ *     mrf_control_prepare   end-effector FK + RF-CV goal estimate                 (EXJ:325-329, 346-348)
+ *     mrf_rollout           Rollout Fabrics -> mean squared velocity per robot    (EXJ:354-375)
+ *     mrf_deadlock_step     deadlock detection / resolution                      (EXJ:377-383, DP:50-118)
+ *     mrf_compute_action_coupled                                                 (EXJ:394-448)
+ *     mrf_apply_action      clip + exact velocity integration                     (EXJ:452-453, urdfenvs 'vel' mode)
+ * mrf_episode_run chains them for n_steps control steps without a host round trip (optionally as a replayed HIP graph).
+ */
+typedef struct mrf_deadlock_config { /* thresholds of deadlock_prevention.py:12-27 and the literals of :50-118 */
+  double avg_vel_constant;     /* DP:20 (0.16; point masses DP:13 0.03)  deadlock if avg velocity signal below */
+  double dist_constant;        /* DP:21 (0; 1)        ... and the pair's summed goal distance above            */
+  double goal_weight_follower; /* DP:22 (2; 10) */
+  double goal_weight_leader;   /* DP:23 (3; 1)  */
+  double nr_goal_scale;        /* DP:25 (2; 100) */
+  double ee_distance;          /* DP:63  0.35   ... and the end effectors closer than this                     */
+  double follower_offset;      /* DP:95  0.3    follower goal = x_follower - offset * unit(x_leader - x_follower) */
+  double min_goal_norm;        /* DP:94  0.05   */
+  double z_floor;              /* DP:98-99 0.1  replaces a negative follower-goal height                       */
+  int32_t time_wait;           /* DP:24 (300; 50) steps the resolution is held after the deadlock disappears   */
+  int32_t min_time_step;       /* DP:66,81  10 */
+  int32_t grasp_state;         /* DP:108  2   state-machine state that cancels the hold ...                    */
+  int32_t grasp_timeout;       /* DP:109  400 ... by setting time_deadlock_out to this                         */
+} mrf_deadlock_config;
+void mrf_default_deadlock_config(mrf_deadlock_config* c, int32_t point_mass);
+
+/* per-scenario deadlock state, int32 dl_state[MRF_DL_NSTATE][n_scenarios] + scalar dl_goal[3][n_scenarios]
+ * (= the attributes of the reference's deadlockprevention object that its logic reads back, DP:9-34) */
+#define MRF_DL_LEADER 0
+#define MRF_DL_FOLLOWER 1
+#define MRF_DL_DEAD0 2
+#define MRF_DL_DEAD1 3
+#define MRF_DL_TIME_IN_DEADLOCK 4
+#define MRF_DL_TIME_DEADLOCK_OUT 5 /* the driver's loop variable, initial value 1000 (EXJ:273) */
+#define MRF_DL_TIME_STEP 6         /* control-step counter w (EXJ:279), advanced by mrf_deadlock_step */
+#define MRF_DL_NSTATE 7
+int mrf_deadlock_init(mrf_handle* h, int64_t n_scenarios, int32_t* dl_state, void* dl_goal, void* stream);
+
+/* rows = n_scenarios * n_robots.  Copies params_nominal to params_work (they may alias), writes the hand position
+ * x_ee [3][rows] and, when apply_estimate != 0, overwrites x_goal_0 in params_work with x_ee + goal_estimate_T * v_ee
+ * for the robots in cfg.goal_estimate_mask -- as the reference does, where the estimate then also reaches
+ * deadlock_checking and compute_action (EXJ:346-348 -> :377, :425).  With apply_estimate == 0 the estimate stays
+ * inside mrf_rollout (which applies the same mask itself) and the other stages see the true goals. */
+int mrf_control_prepare(mrf_handle* h, int64_t n_scenarios, const void* q, const void* qdot, const void* params_nominal,
+                        void* params_work, int32_t apply_estimate, void* x_ee_out, void* stream);
+
+/* Replaces deadlockprevention.deadlock_checking (DP:50-118) for every scenario: avg_sum = sum_i avg_vel[i] / N
+ * (EXJ:375), x_robots = x_ee, goals / weights = x_goal_0 / weight_goal_0 of params_work (rewritten in place for the
+ * leader and the follower), sm_state [rows] the robots' state-machine states (NULL = all 0, "approaching").
+ * time_step < 0 uses (and advances) the device counter MRF_DL_TIME_STEP; otherwise the given step is used. */
+int mrf_deadlock_step(mrf_handle* h, int64_t n_scenarios, const mrf_deadlock_config* dl, int32_t time_step,
+                      const void* x_ee, const void* avg_vel, const int32_t* sm_state, void* params_work,
+                      int32_t* dl_state, void* dl_goal, void* stream);
+
+/* action := clip(action, +-vel_limit) (EXJ:452; vel_limit [dof] host array), q += dt * action, qdot := action
+ * (mode 'vel').  stop_margin >= 0 additionally clamps q to [lo + margin, hi - margin] of cfg.limits, the hard joint
+ * stops a simulator imposes; < 0 disables it. */
+int mrf_apply_action(mrf_handle* h, int64_t rows, void* q_io, void* qdot_io, void* action_io, const double* vel_limit,
+                     double stop_margin, void* stream);
+
+/* n_steps control steps on the device.  h_rollout may be NULL (no Rollout Fabrics, no deadlock logic: plain MRDF);
+ * dl may be NULL (rollouts monitored, no deadlock logic).  Work buffers are caller-owned:
+ *   params_work [MRF_NPARAM][rows]  x_ee_work [3][rows]  avg_work [rows]  action_out [dof][rows] (last step's action)
+ * use_graph != 0 captures one control step into a HIP graph (cached in h_action) and replays it. */
+int mrf_episode_run(mrf_handle* h_rollout, mrf_handle* h_action, int64_t n_scenarios, int32_t n_steps,
+                    const mrf_deadlock_config* dl, int32_t apply_estimate, const double* vel_limit, double stop_margin,
+                    void* q_io, void* qdot_io, const void* params_nominal, void* params_work, const int32_t* sm_state,
+                    int32_t* dl_state, void* dl_goal, void* x_ee_work, void* avg_work, void* action_out,
+                    int32_t use_graph, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

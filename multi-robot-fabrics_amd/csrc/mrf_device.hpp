@@ -743,6 +743,18 @@ struct PandaState {
   T q[7], qd[7], cq[7], sq[7];
 };
 
+// ---------------------------------------------------------------------------- row state
+template <typename T>
+__device__ __forceinline__ void load_state(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
+                                           PandaState<T>& R) {
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    R.q[j] = q[j * rows + r];
+    R.qd[j] = qd[j * rows + r];
+    m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+  }
+}
+
 template <typename T, class PRM>
 __device__ __forceinline__ void panda_ego_points(const PandaKin<T>& K, const PRM& prm, EgoPts<T, NG>& E) {
   constexpr int jo[4] = {2, 3, 4, 6};  // joint-origin index of links 3, 4, 5(=6), 7

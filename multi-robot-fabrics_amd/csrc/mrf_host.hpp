@@ -1,0 +1,50 @@
+// mrf_host.hpp -- host-side state shared by the translation units that implement include/mrf.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/mrf.h"
+
+struct mrf_handle {
+  mrf_config cfg;
+  int device;
+  int64_t coop_max_scen;  // batches up to this size use the cooperative kernels (auto mode)
+  void* dcfg;             // DevCfg<double> or DevCfg<float> on the device
+  std::string err;
+  // mrf_episode_run: cached HIP graph of one control step, the argument tuple it was captured for, and the stream
+  // used when the caller passes the (uncapturable) legacy default stream
+  void* graph_exec = nullptr;
+  std::string graph_key;
+  void* own_stream = nullptr;
+};
+
+namespace mrf_host {
+
+inline int fail(mrf_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+inline int check_hip(mrf_handle* h, hipError_t e, const char* what) {
+  if (e == hipSuccess) return MRF_OK;
+  return fail(h, MRF_E_LAUNCH, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <typename K, typename... Args>
+int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+  hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+  return check_hip(h, hipGetLastError(), "kernel launch");
+}
+
+template <typename F>
+int dispatch_scalar(mrf_handle* h, F f) {
+  return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
+}
+
+}  // namespace mrf_host
+
+#define MRF_CHECK_READY(h)                              \
+  if (!(h)) return MRF_E_ARG;                           \
+  if (!(h)->dcfg) return mrf_host::fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)");

@@ -17,20 +17,9 @@
 #include <string>
 
 #include "mrf_device.hpp"
+#include "mrf_host.hpp"
 
 namespace mrf {
-
-// ---------------------------------------------------------------------------- row state
-template <typename T>
-__device__ __forceinline__ void load_state(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
-                                           PandaState<T>& R) {
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    R.q[j] = q[j * rows + r];
-    R.qd[j] = qd[j * rows + r];
-    m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
-  }
-}
 
 // obstacle loop over HBM arrays [n_obst][3][rows] (compute_action / Cartesian rollout); tk = elapsed obstacle time
 template <class CL, typename T>
@@ -831,15 +820,13 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
 }  // namespace mrf
 
 // ================================================================================ host side / C ABI
-struct mrf_handle {
-  mrf_config cfg;
-  int device;
-  int64_t coop_max_scen;  // batches up to this size use the cooperative kernels (auto mode)
-  void* dcfg;  // DevCfg<double> or DevCfg<float> on the device
-  std::string err;
-};
 
 namespace {
+
+using mrf_host::check_hip;
+using mrf_host::dispatch_scalar;
+using mrf_host::fail;
+using mrf_host::launch;
 
 template <typename T>
 void to_dev_leaf(const mrf_leaf_fn& s, mrf::LeafFn<T>& d) {
@@ -905,16 +892,6 @@ void common_defaults(mrf_config* c) {
   set_leaf(c->plane_finsler, MRF_FAMILY_POW, MRF_GATE_NEG, 1, 0.1, 0, 0);
 }
 
-int fail(mrf_handle* h, int code, const std::string& msg) {
-  if (h) h->err = msg;
-  return code;
-}
-
-int check_hip(mrf_handle* h, hipError_t e, const char* what) {
-  if (e == hipSuccess) return MRF_OK;
-  return fail(h, MRF_E_LAUNCH, std::string(what) + ": " + hipGetErrorString(e));
-}
-
 std::string validate(const mrf_config& c) {
   if (c.abi_version != MRF_ABI_VERSION) return "abi_version mismatch";
   if (c.model != MRF_MODEL_PANDA7 && c.model != MRF_MODEL_PLANAR3) return "unknown model";
@@ -946,12 +923,6 @@ std::string validate(const mrf_config& c) {
     if (f->p < 0 || f->p > 16) return "leaf exponent p must be in 0..16";
   }
   return "";
-}
-
-template <typename K, typename... Args>
-int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args... args) {
-  hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
-  return check_hip(h, hipGetLastError(), "kernel launch");
 }
 
 // the reference's Panda leaf strings (EXJ:87-89 + the library's limit / plane-Finsler defaults) get compile-time
@@ -991,10 +962,6 @@ bool use_coop(const mrf_handle* h, int64_t n_scen) {
   return n_scen <= h->coop_max_scen;
 }
 
-template <typename F>
-int dispatch_scalar(mrf_handle* h, F f) {
-  return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
-}
 template <typename F>
 int dispatch(mrf_handle* h, F f) {
   const bool fast = is_panda_leafset(h->cfg);
@@ -1128,15 +1095,13 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
 
 void mrf_destroy(mrf_handle* h) {
   if (!h) return;
+  if (h->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)h->graph_exec);
+  if (h->own_stream) (void)hipStreamDestroy((hipStream_t)h->own_stream);
   if (h->dcfg) (void)hipFree(h->dcfg);
   delete h;
 }
 
 const char* mrf_last_error(const mrf_handle* h) { return h ? h->err.c_str() : "null handle"; }
-
-#define MRF_CHECK_READY(h)                              \
-  if (!(h)) return MRF_E_ARG;                           \
-  if (!(h)->dcfg) return fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)");
 
 int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
                        int32_t n_obst, int32_t n_obst_static, const void* ox, const void* ov, const void* oa,

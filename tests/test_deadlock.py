@@ -1,0 +1,32 @@
+"""Deadlock detection / resolution (DP:50-118) against sequences recorded from the reference's own
+module (tests/golden/make_deadlock_golden.py imports it in the build container; only inputs/outputs are stored)."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "deadlock_sequences.npz"))
+CASES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def case(name):
+    return {k.split("/")[1]: GOLD[k] for k in GOLD.files if k.startswith(name + "/")}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_host_mirror_replays_reference_sequences(name):
+    from multi_robot_fabrics_amd.deadlock import deadlockprevention
+    c = case(name)
+    n = c["x"].shape[1]
+    dp = deadlockprevention([2 if name.startswith("point") else 7] * n, n, 10)
+    for t in range(c["x"].shape[0]):
+        g, w, t_out = dp.deadlock_checking([x.copy() for x in c["x"][t]], [g.copy() for g in c["goals_in"][t]],
+                                           list(c["weights_in"][t]), int(c["time_step"][t]), int(c["t_out_in"][t]),
+                                           float(c["avg"][t]), list(c["sm"][t]))
+        assert t_out == c["t_out_out"][t], (name, t)
+        np.testing.assert_array_equal(np.array(g, dtype=float), c["goals_out"][t])
+        np.testing.assert_array_equal(np.array(w, dtype=float), c["weights_out"][t])
+        assert (dp.i_leader, dp.i_follower) == (c["leader"][t], c["follower"][t])
+        assert list(dp.i_robots_dead) == list(c["dead"][t])
+        assert dp.time_in_deadlock == c["time_in_deadlock"][t]
