@@ -78,7 +78,21 @@ EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
     "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
     "mrf_fk_spheres", "mrf_step_predict", "mrf_step_action",
+    "mrf_default_deadlock_config", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
+    "mrf_episode_run",
 ]
+
+# rows of the int32 deadlock state (include/mrf.h MRF_DL_*)
+DL_LEADER, DL_FOLLOWER, DL_DEAD0, DL_DEAD1, DL_TIME_IN_DEADLOCK, DL_TIME_DEADLOCK_OUT, DL_TIME_STEP, DL_NSTATE = range(8)
+
+
+class DeadlockConfig(C.Structure):
+    """ctypes mirror of mrf_deadlock_config (thresholds of deadlock_prevention.py:12-27, literals of :50-118)."""
+    _fields_ = [("avg_vel_constant", C.c_double), ("dist_constant", C.c_double), ("goal_weight_follower", C.c_double),
+                ("goal_weight_leader", C.c_double), ("nr_goal_scale", C.c_double), ("ee_distance", C.c_double),
+                ("follower_offset", C.c_double), ("min_goal_norm", C.c_double), ("z_floor", C.c_double),
+                ("time_wait", C.c_int32), ("min_time_step", C.c_int32), ("grasp_state", C.c_int32),
+                ("grasp_timeout", C.c_int32)]
 
 _lib = None
 
@@ -130,6 +144,20 @@ def load_library(path=None):
     lib.mrf_step_predict.restype = C.c_int
     lib.mrf_step_action.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.mrf_step_action.restype = C.c_int
+    dlp = C.POINTER(DeadlockConfig)
+    lib.mrf_default_deadlock_config.argtypes = [dlp, i32]
+    lib.mrf_default_deadlock_config.restype = None
+    lib.mrf_deadlock_init.argtypes = [vp, i64, vp, vp, vp]
+    lib.mrf_deadlock_init.restype = C.c_int
+    lib.mrf_control_prepare.argtypes = [vp, i64, vp, vp, vp, vp, i32, vp, vp]
+    lib.mrf_control_prepare.restype = C.c_int
+    lib.mrf_deadlock_step.argtypes = [vp, i64, dlp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_deadlock_step.restype = C.c_int
+    lib.mrf_apply_action.argtypes = [vp, i64, vp, vp, vp, C.POINTER(C.c_double), C.c_double, vp]
+    lib.mrf_apply_action.restype = C.c_int
+    lib.mrf_episode_run.argtypes = [vp, vp, i64, i32, dlp, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, vp, vp,
+                                    vp, vp, vp, vp, vp, i32, vp]
+    lib.mrf_episode_run.restype = C.c_int
     if lib.mrf_abi_version() != MRF_ABI_VERSION:
         raise MrfLibraryError(f"ABI mismatch: library {lib.mrf_abi_version()} != python {MRF_ABI_VERSION}")
     if lib.mrf_config_sizeof() != C.sizeof(Config):

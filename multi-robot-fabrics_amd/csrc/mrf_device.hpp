@@ -57,6 +57,8 @@ __device__ __forceinline__ double m_abs(double x) { return ::fabs(x); }
 __device__ __forceinline__ float m_abs(float x) { return ::fabsf(x); }
 __device__ __forceinline__ double m_max(double a, double b) { return ::fmax(a, b); }
 __device__ __forceinline__ float m_max(float a, float b) { return ::fmaxf(a, b); }
+__device__ __forceinline__ double m_min(double a, double b) { return ::fmin(a, b); }
+__device__ __forceinline__ float m_min(float a, float b) { return ::fminf(a, b); }
 __device__ __forceinline__ void m_sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
 __device__ __forceinline__ void m_sincos(float x, float* s, float* c) { ::sincosf(x, s, c); }
 

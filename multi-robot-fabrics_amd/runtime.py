@@ -186,3 +186,97 @@ class FabricHandle:
                                       self._arg(sph_all, (N, S, 9, n_scen), "sph_all"),
                                       self._arg(sumsq_io, (rows,), "sumsq_io"), self._stream(stream))
         self._check(rc)
+
+
+    # ------------------------------------------------------------------ device-resident control step (include/mrf.h)
+    def control_prepare(self, q, qdot, params_nominal, params_work, apply_estimate=True, stream=None):
+        """Hand FK + RF-CV goal estimate (EXJ:325-329,346-348) -> x_ee [3,rows]; fills params_work."""
+        rows = q.shape[1]
+        x_ee = torch.empty((3, rows), dtype=self.dtype, device=self.device)
+        rc = self.lib.mrf_control_prepare(self._h, rows // self.cfg.n_robots, self._arg(q, (self.dof, rows), "q"),
+                                          self._arg(qdot, (self.dof, rows), "qdot"),
+                                          self._arg(params_nominal, (abi.NPARAM, rows), "params_nominal"),
+                                          self._arg(params_work, (abi.NPARAM, rows), "params_work"),
+                                          int(bool(apply_estimate)), self._arg(x_ee), self._stream(stream))
+        self._check(rc)
+        return x_ee
+
+    def deadlock_state(self, n_scen, stream=None):
+        """Fresh per-scenario deadlock state: (int32 [DL_NSTATE, n_scen], goal [3, n_scen])  (DP:9-34, EXJ:273)."""
+        st = torch.empty((abi.DL_NSTATE, n_scen), dtype=torch.int32, device=self.device)
+        goal = torch.empty((3, n_scen), dtype=self.dtype, device=self.device)
+        self._check(self.lib.mrf_deadlock_init(self._h, n_scen, C.c_void_p(st.data_ptr()), self._arg(goal),
+                                               self._stream(stream)))
+        return st, goal
+
+    def deadlock_config(self, point_mass=False):
+        c = abi.DeadlockConfig()
+        self.lib.mrf_default_deadlock_config(C.byref(c), int(bool(point_mass)))
+        return c
+
+    @staticmethod
+    def _i32(t, shape, name):
+        if t is None:
+            return None
+        if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+            raise MrfError(f"{name}: expected a contiguous int32 device tensor of shape {tuple(shape)}")
+        return C.c_void_p(t.data_ptr())
+
+    def deadlock_step(self, dl_cfg, x_ee, avg_vel, params_work, dl_state, dl_goal, sm_state=None, time_step=-1,
+                      stream=None):
+        """deadlock_checking (DP:50-118) for every scenario; rewrites x_goal_0 / weight_goal_0 rows of params_work."""
+        rows = x_ee.shape[1]
+        n_scen = rows // self.cfg.n_robots
+        rc = self.lib.mrf_deadlock_step(self._h, n_scen, C.byref(dl_cfg), int(time_step), self._arg(x_ee, (3, rows), "x_ee"),
+                                        self._arg(avg_vel, (rows,), "avg_vel"), self._i32(sm_state, (rows,), "sm_state"),
+                                        self._arg(params_work, (abi.NPARAM, rows), "params_work"),
+                                        self._i32(dl_state, (abi.DL_NSTATE, n_scen), "dl_state"),
+                                        self._arg(dl_goal, (3, n_scen), "dl_goal"), self._stream(stream))
+        self._check(rc)
+
+    def apply_action(self, q_io, qdot_io, action_io, vel_limit, stop_margin=-1.0, stream=None):
+        """action := clip(action, +-vel_limit); q += dt*action; qdot := action  (EXJ:452-453)."""
+        rows = q_io.shape[1]
+        vl = (C.c_double * 7)(*[float(v) for v in vel_limit])
+        rc = self.lib.mrf_apply_action(self._h, rows, self._arg(q_io, (self.dof, rows), "q_io"),
+                                       self._arg(qdot_io, (self.dof, rows), "qdot_io"),
+                                       self._arg(action_io, (self.dof, rows), "action_io"), vl, float(stop_margin),
+                                       self._stream(stream))
+        self._check(rc)
+
+
+class ControlLoop:
+    """n control steps on the device without a host round trip (mrf_episode_run): per step
+    prepare -> Rollout Fabrics -> deadlock logic -> coupled compute_action -> apply (EXJ:280-458 minus the simulator).
+
+    `h_rollout` may be None (plain MRDF: no rollouts, no deadlock logic); `deadlock=False` keeps the rollouts as a
+    monitor only.  State (q, qdot, deadlock state) lives in this object's device tensors and is advanced in place."""
+
+    def __init__(self, h_action, h_rollout, q, qdot, params, vel_limit, deadlock=True, apply_estimate=True,
+                 stop_margin=1e-3, sm_state=None, use_graph=True):
+        self.ha, self.hr = h_action, h_rollout
+        self.q, self.qdot, self.params = q.clone(), qdot.clone(), params
+        rows = q.shape[1]
+        self.n_scen = rows // h_action.cfg.n_robots
+        self.params_work = torch.empty_like(params)
+        self.x_ee = torch.empty((3, rows), dtype=h_action.dtype, device=h_action.device)
+        self.avg = torch.zeros((rows,), dtype=h_action.dtype, device=h_action.device)
+        self.action = torch.zeros_like(q)
+        self.vel_limit = (C.c_double * 7)(*[float(v) for v in vel_limit])
+        self.stop_margin = float(stop_margin)
+        self.apply_estimate = bool(apply_estimate)
+        self.sm_state = sm_state
+        self.use_graph = bool(use_graph)
+        self.dl_cfg = h_action.deadlock_config() if (deadlock and h_rollout is not None) else None
+        self.dl_state, self.dl_goal = (h_rollout.deadlock_state(self.n_scen) if self.dl_cfg is not None else (None, None))
+
+    def run(self, n_steps, stream=None):
+        ha, hr = self.ha, self.hr
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        rc = ha.lib.mrf_episode_run(hr._h if hr is not None else None, ha._h, self.n_scen, int(n_steps),
+                                    C.byref(self.dl_cfg) if self.dl_cfg is not None else None, int(self.apply_estimate),
+                                    self.vel_limit, self.stop_margin, p(self.q), p(self.qdot), p(self.params),
+                                    p(self.params_work), p(self.sm_state), p(self.dl_state), p(self.dl_goal), p(self.x_ee),
+                                    p(self.avg), p(self.action), int(self.use_graph), FabricHandle._stream(stream))
+        ha._check(rc)
+        return self.action

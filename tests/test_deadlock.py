@@ -30,3 +30,24 @@ def test_host_mirror_replays_reference_sequences(name):
         assert (dp.i_leader, dp.i_follower) == (c["leader"][t], c["follower"][t])
         assert list(dp.i_robots_dead) == list(c["dead"][t])
         assert dp.time_in_deadlock == c["time_in_deadlock"][t]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_replays_reference_sequences(name):
+    """The oracle used by the GPU parity tests is itself pinned by the reference's recorded sequences."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import deadlock_oracle as do
+    c = case(name)
+    K = do.constants(point_mass=name.startswith("point"))
+    st = do.initial_state()
+    for t in range(c["x"].shape[0]):
+        st["time_deadlock_out"] = int(c["t_out_in"][t])      # the driver owns this variable (EXJ:273,377-383)
+        st, g, w = do.step(st, K, c["x"][t], c["goals_in"][t], c["weights_in"][t], float(c["avg"][t]),
+                           int(c["time_step"][t]), [int(v) for v in c["sm"][t]])
+        assert st["time_deadlock_out"] == c["t_out_out"][t], (name, t)
+        np.testing.assert_allclose(g, c["goals_out"][t], rtol=0, atol=1e-15)
+        np.testing.assert_array_equal(w, c["weights_out"][t])
+        assert (st["leader"], st["follower"]) == (c["leader"][t], c["follower"][t])
+        assert list(st["dead"]) == list(c["dead"][t])
+        assert st["time_in_deadlock"] == c["time_in_deadlock"][t]

@@ -1,0 +1,184 @@
+"""GPU parity of the device-resident control step (include/mrf.h "Device-resident control step").
+
+ * mrf_deadlock_step against the sequences recorded from the reference's own deadlock_prevention module (integer
+   decisions exact, rewritten goals to 1e-12) and against the pinned oracle on large random batches;
+ * mrf_control_prepare / mrf_apply_action against numpy;
+ * mrf_episode_run (plain launches and replayed HIP graph) against the oracle-side episode, f64 <= 1e-8 relative on q
+   after 25 closed-loop steps (errors of the 1e-9 single-step tolerance accumulate through the recurrence).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.runtime import ControlLoop, FabricHandle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "deadlock_sequences.npz"))
+CASES = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def case(name):
+    return {k.split("/")[1]: GOLD[k] for k in GOLD.files if k.startswith(name + "/")}
+
+
+def relerr(got, want):
+    return float(np.abs(got - want).max() / max(1e-300, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_deadlock_step_replays_reference_sequences(name):
+    c = case(name)
+    T, N = c["x"].shape[:2]
+    cfg = config.panda_config(n_robots=N, horizon=1)
+    h = FabricHandle(cfg, 0)
+    dl = h.deadlock_config(point_mass=name.startswith("point"))
+    st, goal = h.deadlock_state(1)
+    prm = torch.zeros((abi.NPARAM, N), dtype=torch.float64, device="cuda")
+    for t in range(T):
+        prm[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3] = h.tensor(c["goals_in"][t].T)
+        prm[abi.P_WEIGHT_GOAL_0] = h.tensor(c["weights_in"][t])
+        x_ee = h.tensor(np.ascontiguousarray(c["x"][t].T))
+        avg = h.tensor(np.full(N, c["avg"][t]))
+        sm = torch.as_tensor(c["sm"][t], dtype=torch.int32, device="cuda").contiguous()
+        h.deadlock_step(dl, x_ee, avg, prm, st, goal, sm_state=sm, time_step=int(c["time_step"][t]))
+        s = st.cpu().numpy()[:, 0]
+        assert s[abi.DL_TIME_DEADLOCK_OUT] == c["t_out_out"][t], (name, t)
+        assert (s[abi.DL_LEADER], s[abi.DL_FOLLOWER]) == (c["leader"][t], c["follower"][t]), (name, t)
+        assert [s[abi.DL_DEAD0], s[abi.DL_DEAD1]] == list(c["dead"][t])
+        assert s[abi.DL_TIME_IN_DEADLOCK] == c["time_in_deadlock"][t]
+        assert s[abi.DL_TIME_STEP] == c["time_step"][t] + 1
+        p = prm.cpu().numpy()
+        np.testing.assert_allclose(p[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3].T, c["goals_out"][t], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(p[abi.P_WEIGHT_GOAL_0], c["weights_out"][t])
+
+
+@pytest.mark.parametrize("scalar,n_robots", [(abi.F64, 3), (abi.F64, 8), (abi.F32, 2)])
+def test_deadlock_step_random_batches(scalar, n_robots):
+    """Many independent scenarios advanced together vs the (reference-pinned) oracle, device step counter in use."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import deadlock_oracle as do
+    N, B, T = n_robots, 257, 40
+    cfg = config.panda_config(n_robots=N, horizon=1)
+    cfg.scalar = scalar
+    h = FabricHandle(cfg, 0)
+    dl = h.deadlock_config()
+    K = do.constants()
+    rng = np.random.default_rng(5)
+    rows = B * N
+    np_t = np.float64 if scalar == abi.F64 else np.float32
+    st, goal = h.deadlock_state(B)
+    states = [do.initial_state() for _ in range(B)]
+    x = (rng.uniform(-0.2, 0.2, (3, rows)) + np.array([[0.0], [0.0], [0.3]])).astype(np_t).astype(float)
+    goals0 = rng.uniform(-0.6, 0.6, (3, rows))
+    for t in range(T):
+        x = (x + rng.normal(0, 0.03, x.shape)).astype(np_t).astype(float)     # representable in the kernel's type
+        prm = np.zeros((abi.NPARAM, rows))
+        prm[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3] = goals0.astype(np_t)
+        prm[abi.P_WEIGHT_GOAL_0] = 2.0
+        avg = rng.choice([0.01, 0.3, 1.0], size=rows).astype(np_t).astype(float)
+        sm = rng.choice([0, 1, 2, 3], size=rows, p=[0.5, 0.3, 0.1, 0.1]).astype(np.int32)
+        states, want = do.step_batch(states, K, x, prm, avg, t, sm, N)
+        d_prm = h.tensor(prm)
+        h.deadlock_step(dl, h.tensor(x), h.tensor(avg), d_prm, st, goal, sm_state=torch.as_tensor(sm, device="cuda"))
+        got = d_prm.cpu().numpy().astype(float)
+        s = st.cpu().numpy()
+        assert [int(v) for v in s[abi.DL_LEADER]] == [a["leader"] for a in states], t
+        assert [int(v) for v in s[abi.DL_FOLLOWER]] == [a["follower"] for a in states], t
+        assert [int(v) for v in s[abi.DL_TIME_DEADLOCK_OUT]] == [a["time_deadlock_out"] for a in states], t
+        assert [int(v) for v in s[abi.DL_TIME_IN_DEADLOCK]] == [a["time_in_deadlock"] for a in states], t
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 if scalar == abi.F64 else 1e-5)
+    assert sum(a["time_in_deadlock"] for a in states) > 100      # the resolution branch was exercised
+
+
+def test_prepare_and_apply_match_numpy(oracle):
+    N, B = 3, 37
+    cfg = config.panda_config(n_robots=N, horizon=5)
+    cfg.goal_estimate_mask = 0b110
+    batch = scenarios.panda_batch(cfg, B, seed=11)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    work = torch.empty_like(prm)
+    x_ee = h.control_prepare(q, qd, prm, work, apply_estimate=True)
+    sx, sv, _ = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    assert relerr(x_ee.cpu().numpy(), sx[7]) < 1e-12
+    want = batch["params"].copy()
+    for i in (1, 2):
+        want[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3, i::N] = sx[7][:, i::N] + cfg.goal_estimate_T * sv[7][:, i::N]
+    assert relerr(work.cpu().numpy(), want) < 1e-12
+    work2 = torch.empty_like(prm)
+    h.control_prepare(q, qd, prm, work2, apply_estimate=False)
+    assert torch.equal(work2, prm)
+    rng = np.random.default_rng(0)
+    act = rng.uniform(-4, 4, batch["q"].shape)
+    q0 = batch["q"].copy()
+    q0[3, :5] = cfg.limits[3][1] - 1e-4                                       # next to a hard stop
+    dq, dqd, dact = h.tensor(q0), h.tensor(batch["qdot"]), h.tensor(act)
+    h.apply_action(dq, dqd, dact, config.PANDA_VEL_LIMITS, stop_margin=1e-3)
+    vl = np.array(config.PANDA_VEL_LIMITS)[:, None]
+    a = np.clip(act, -vl, vl)
+    lim = np.array(config.PANDA_LIMITS)
+    qn = np.minimum(np.maximum(q0 + cfg.dt * a, lim[:, 0:1] + 1e-3), lim[:, 1:2] - 1e-3)
+    np.testing.assert_allclose(dq.cpu().numpy(), qn, rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(dqd.cpu().numpy(), a)
+    np.testing.assert_array_equal(dact.cpu().numpy(), a)
+
+
+@pytest.mark.parametrize("n_robots,use_graph,apply_estimate,kernel", [(3, False, True, 1), (3, True, True, 2),
+                                                                      (2, True, False, 0), (3, True, False, 1)])
+def test_episode_matches_oracle_episode(oracle, n_robots, use_graph, apply_estimate, kernel):
+    import oracle_episode as oe
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+    import deadlock_oracle as do
+    N, B, STEPS = n_robots, 5, 25
+    cfg_roll = config.panda_config(n_robots=N, horizon=6)
+    cfg_roll.goal_estimate_mask = 0b110 & ((1 << N) - 1)
+    cfg_roll.kernel_select = kernel
+    cfg_act = config.panda_config(n_robots=N, horizon=1)
+    cfg_act.kernel_select = kernel
+    batch = scenarios.panda_batch(cfg_roll, B, seed=21, qd_spread=0.2)
+    hr, ha = FabricHandle(cfg_roll, 0), FabricHandle(cfg_act, 0)
+    q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    loop = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=True, apply_estimate=apply_estimate,
+                       stop_margin=1e-3, use_graph=use_graph)
+    # thresholds opened up so that the resolution branch is active from step 11 on in every scenario
+    loop.dl_cfg.avg_vel_constant = 1e9
+    loop.dl_cfg.ee_distance = 10.0
+    K = do.constants()
+    K["avg_vel_constant"], K["ee_distance"] = 1e9, 10.0
+    loop.run(10)
+    loop.run(STEPS - 10)      # second call: cached graph / continued device step counter
+    torch.cuda.synchronize()
+    wq, wqd, wact, states, hist = oe.episode(cfg_roll, cfg_act, batch["q"], batch["qdot"], batch["params"], STEPS, K,
+                                             config.PANDA_VEL_LIMITS, 1e-3, apply_estimate=apply_estimate)
+    assert relerr(loop.q.cpu().numpy(), wq) < 1e-8
+    assert relerr(loop.action.cpu().numpy(), wact) < 1e-7
+    assert relerr(loop.params_work.cpu().numpy(), hist[-1]["work"]) < 1e-8
+    assert relerr(loop.avg.cpu().numpy(), hist[-1]["avg"]) < 1e-7
+    s = loop.dl_state.cpu().numpy()
+    assert [int(v) for v in s[abi.DL_TIME_IN_DEADLOCK]] == [a["time_in_deadlock"] for a in states]
+    assert [int(v) for v in s[abi.DL_LEADER]] == [a["leader"] for a in states]
+    assert all(int(v) == STEPS for v in s[abi.DL_TIME_STEP])
+    assert min(a["time_in_deadlock"] for a in states) == STEPS - 11
+
+
+def test_episode_without_rollouts_is_plain_mrdf(oracle):
+    """h_rollout = None: compute_action + apply only (BASELINE config 2 stepped in closed loop)."""
+    N, B, STEPS = 2, 9, 12
+    cfg = config.panda_config(n_robots=N, horizon=1)
+    batch = scenarios.panda_batch(cfg, B, seed=4, qd_spread=0.2)
+    ha = FabricHandle(cfg, 0)
+    q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    loop = ControlLoop(ha, None, q, qd, prm, config.PANDA_VEL_LIMITS, use_graph=True)
+    loop.run(STEPS)
+    qq, qdd = q.clone(), qd.clone()
+    for _ in range(STEPS):
+        act = ha.compute_action_coupled(qq, qdd, prm)
+        ha.apply_action(qq, qdd, act, config.PANDA_VEL_LIMITS, stop_margin=1e-3)
+    assert torch.equal(loop.q, qq) and torch.equal(loop.qdot, qdd)

@@ -12,4 +12,6 @@ if [ -n "$rev" ] && [ "$rev" != "-" ]; then
   src=$(mktemp -d)
   git archive "$rev" multi-robot-fabrics_amd/csrc include | tar -x -C "$src"
 fi
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" -o ab/lib$name.so "$src/multi-robot-fabrics_amd/csrc/mrf_kernels.hip"
+srcs="$src/multi-robot-fabrics_amd/csrc/mrf_kernels.hip"
+[ -f "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" ] && srcs="$srcs $src/multi-robot-fabrics_amd/csrc/mrf_control.hip"
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" -o ab/lib$name.so $srcs
