@@ -20,12 +20,16 @@ for name, N, H, S20, rounds in (("C3 2-Panda RF H=20", 2, 20, False, 6), ("C4 3-
         b = scenarios.panda_batch(cfg, B, seed=5, x_min=0.3 if N == 8 else 0.05, q_spread=0.15 if N == 8 else 0.3)
         h = FabricHandle(cfg, 0)
         q, qd, prm = (h.tensor(b[k]) for k in ("q", "qdot", "params"))
-        h.rollout(q, qd, prm); torch.cuda.synchronize()
-        t0 = time.perf_counter()
         for _ in range(3):
             h.rollout(q, qd, prm)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            h.rollout(q, qd, prm)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) * 1e-3 / 10
         sb = 8 if dtype == "f64" else 4
         S = cfg.n_spheres
         bytes_unit = sb * (28 + 9 * S * N) + sb * 23 / H
