@@ -34,7 +34,11 @@ struct LeafFn {
 template <typename T>
 struct DevCfg {
   int model, mode, n_robots, n_spheres, horizon, dynamic, n_ego, n_planes;
-  int use_limits, n_goals, plane_abs, zero_small, obst_dim, goal_mask, pad0, pad1;
+  int use_limits, n_goals, plane_abs, zero_small, obst_dim, goal_mask;
+  // Link-origin sphere table: panda_joint2 and panda_joint6 have zero origin offsets (URDF), so the origins of links
+  // 1/2 and of links 5/6 coincide with identical velocity and Jdot*qdot.  When their radii are equal too, the two
+  // spheres produce the same leaf twice: the coupled kernels evaluate it once with weight 2 (set by the host).
+  int lo_merge01, lo_merge45;
   T dt, eps, jsign, goal_T, base_mass;
   T attr_k, attr_alpha, attr_mu, attr_ml, attr_a;
   T beta_a, beta_r, beta_b, beta_s, eta_a, eta_s;
@@ -506,7 +510,8 @@ __device__ __forceinline__ void collision_leaf(const DevCfg<T>& cfg, T d, T nv, 
 // a_o is the obstacle's reference acceleration as the reference passes it (already sign-carrying).
 template <class CL, typename T, int NP>
 __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const EgoPts<T, NP>& E, const T* xo,
-                                                    const T* vo, const T* a_o, T ro, bool planar, EgoAcc<T, NP>& acc) {
+                                                    const T* vo, const T* a_o, T ro, bool planar, EgoAcc<T, NP>& acc,
+                                                    T mult = T(1)) {  // mult: multiplicity of coincident spheres
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
     T dx[3] = {E.p[g][0] - xo[0], E.p[g][1] - xo[1], planar ? T(0) : E.p[g][2] - xo[2]};
@@ -521,7 +526,7 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
     T curv = cfg.jsign * kap - na;
     T cl = T(0), cgnv2 = T(0);
     if constexpr (!CL::generic) {
-      cl = T(2) * cfg.cf.k * gate_value<T>(CL::gl, nv);  // sign(xd) == sign(nv), R > 0
+      cl = (T(2) * mult) * cfg.cf.k * gate_value<T>(CL::gl, nv);  // sign(xd) == sign(nv), R > 0
       cgnv2 = cfg.cg.k * gate_value<T>(CL::gg, nv) * nv * nv;
     }
     T wM, wf;  // every ego point carries at least one link (nl >= 1)
@@ -531,6 +536,10 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
       collision_leaf<CL>(cfg, d, nv, ro + E.rb[g][1], curv, cl, cgnv2, wm2, wf2);
       wM += wm2;
       wf += wf2;
+    }
+    if constexpr (CL::generic) {
+      wM *= mult;
+      wf *= mult;
     }
     T w0 = wM * n[0], w1 = wM * n[1], w2 = wM * n[2];
     acc.A[g][0] += w0 * n[0];

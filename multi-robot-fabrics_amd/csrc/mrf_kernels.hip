@@ -122,19 +122,35 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 // origins, velocities and Jdot*qdot from its own chain walk, so it stages them once in a per-wave LDS tile
 // [72][64] (8 links x (x, v, a)) and reads the other robots' entries from there -- no lane re-walks another
 // robot's chain.  4 resident waves x 36.9 KB (f64) fit the CU's 160 KB.
+// slot of link-origin sphere sp (0..7) in the tile once coincident spheres are merged (DevCfg::lo_merge*)
+__device__ __forceinline__ int lo_slot(int sp, int m01, int m45) { return sp - (sp >= 1 ? m01 : 0) - (sp >= 5 ? m45 : 0); }
+// first sphere of a slot and the number of spheres merged into it
+__device__ __forceinline__ int lo_sphere(int slot, int m01, int m45) {
+  const int sp = slot + (slot >= 1 ? m01 : 0);
+  return sp + (sp >= 5 ? m45 : 0);
+}
+__device__ __forceinline__ int lo_count(int slot, int m01, int m45) {
+  return ((slot == 0 && m01) || (slot == 4 - m01 && m45)) ? 2 : 1;
+}
+
 template <typename T>
 __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int lane, const PandaKin<T>& K, bool dyn,
-                                                      bool acc_on, T jsign) {
-  // dyn / acc_on are wave-uniform: branch once instead of selecting per value
+                                                      bool acc_on, T jsign, int m01, int m45) {
+  // dyn / acc_on are wave-uniform: branch once instead of selecting per value.  Merged duplicates write the same
+  // values into the same slot.
 #pragma unroll
-  for (int sp = 0; sp < 8; ++sp)
+  for (int sp = 0; sp < 8; ++sp) {
+    T* dst = tile + lo_slot(sp, m01, m45) * 9 * 64 + lane;
 #pragma unroll
-    for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + k3) * 64 + lane] = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
+    for (int k3 = 0; k3 < 3; ++k3) dst[k3 * 64] = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
+  }
   if (dyn) {
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp)
+    for (int sp = 0; sp < 8; ++sp) {
+      T* dst = tile + lo_slot(sp, m01, m45) * 9 * 64 + lane;
 #pragma unroll
-      for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + 3 + k3) * 64 + lane] = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
+      for (int k3 = 0; k3 < 3; ++k3) dst[(3 + k3) * 64] = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
+    }
   } else {
 #pragma unroll
     for (int sp = 0; sp < 8; ++sp)
@@ -143,10 +159,11 @@ __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int l
   }
   if (acc_on) {
 #pragma unroll
-    for (int sp = 0; sp < 8; ++sp)
+    for (int sp = 0; sp < 8; ++sp) {
+      T* dst = tile + lo_slot(sp, m01, m45) * 9 * 64 + lane;
 #pragma unroll
-      for (int k3 = 0; k3 < 3; ++k3)
-        tile[(sp * 9 + 6 + k3) * 64 + lane] = jsign * (sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3]);
+      for (int k3 = 0; k3 < 3; ++k3) dst[(6 + k3) * 64] = jsign * (sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3]);
+    }
   } else {
 #pragma unroll
     for (int sp = 0; sp < 8; ++sp)
@@ -155,36 +172,43 @@ __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int l
   }
 }
 
-constexpr int TILE_RADII = 72 * 64;  // the 8 link-sphere radii follow the [72][64] tile
-constexpr int TILE_SCALARS = TILE_RADII + 8;
+constexpr int TILE_RADII = 72 * 64;  // per slot: sphere radius and multiplicity follow the [72][64] tile
+constexpr int TILE_MULT = TILE_RADII + 8;
+constexpr int TILE_SCALARS = TILE_MULT + 8;
 
 template <typename T>
 __device__ __forceinline__ void stage_sphere_radii(const DevCfg<T>& cfg, T* __restrict__ tile, int lane) {
-  if (lane < 8) tile[TILE_RADII + lane] = cfg.sphere_r[lane];
+  const int m01 = cfg.lo_merge01, m45 = cfg.lo_merge45;
+  if (lane < 8 && !(lane == 1 && m01) && !(lane == 5 && m45)) {
+    const int slot = lo_slot(lane, m01, m45);
+    tile[TILE_RADII + slot] = cfg.sphere_r[lane];
+    tile[TILE_MULT + slot] = ((lane == 0 && m01) || (lane == 4 && m45)) ? T(2) : T(1);
+  }
 }
 
 template <class CL, typename T>
 __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const T* __restrict__ tile, int ls, int li, int N,
                                                     const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-  // One wave per SIMD: nothing else hides the LDS / scalar-load latency, so the next sphere's nine scalars and
-  // radius are fetched before the current sphere's leaves are evaluated (software pipeline, depth 1).
-  const int M = (N - 1) * 8;
+  // One wave per SIMD: nothing else hides the LDS / scalar-load latency, so the next sphere's nine scalars, radius
+  // and multiplicity are fetched before the current sphere's leaves are evaluated (software pipeline, depth 1).
+  const int nsp = 8 - cfg.lo_merge01 - cfg.lo_merge45;  // distinct spheres per robot
+  const int M = (N - 1) * nsp;
   typedef const __attribute__((address_space(3))) T* lds_ptr;
   typedef const volatile __attribute__((address_space(3))) T* lds_vptr;
-  auto address = [&](int m) {
-    const int d = m >> 3, sp = m & 7;
+  auto address = [&](int d, int sp) {
     int jr = li + 1 + d;
     if (jr >= N) jr -= N;
     return (sp * 9) * 64 + ls * N + jr;
   };
-  T nxt[9], rnxt;
+  T nxt[9], rnxt, mnxt;
   {
     // The first fetch is volatile so that the optimizer cannot merge it with the in-loop fetch into one load of
     // a loop-carried address at the top of the loop (which would undo the pipeline).
-    lds_vptr src = (lds_vptr)(tile + address(0));
+    lds_vptr src = (lds_vptr)(tile + address(0, 0));
 #pragma unroll
     for (int k = 0; k < 9; ++k) nxt[k] = src[k * 64];
     rnxt = ((lds_vptr)tile)[TILE_RADII];
+    mnxt = ((lds_vptr)tile)[TILE_MULT];
   }
   if constexpr (!CL::generic) {
     // Have the scalar loads of the leaf constants complete before the loop: the wait-count pass is static, so a
@@ -192,19 +216,26 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
     // just issued -- into every iteration.
     asm volatile("" ::"s"(cfg.jsign), "s"(cfg.cf.k), "s"(cfg.cg.k));
   }
+  int dn = 0, sn = 0;  // (other robot, slot) of the fetched-ahead sphere
 #pragma unroll 1
   for (int m = 0; m < M; ++m) {
-    T cur[9], rcur = rnxt;
+    T cur[9], rcur = rnxt, mcur = mnxt;
 #pragma unroll
     for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
+    if (m + 1 < M) {
+      if (++sn == nsp) {
+        sn = 0;
+        ++dn;
+      }
+    }
     {
-      const int mn = m + 1 < M ? m + 1 : m;
-      lds_ptr src = (lds_ptr)(tile + address(mn));
+      lds_ptr src = (lds_ptr)(tile + address(dn, sn));
 #pragma unroll
       for (int k = 0; k < 9; ++k) nxt[k] = src[k * 64];
-      rnxt = ((lds_ptr)tile)[TILE_RADII + (mn & 7)];  // staged once per kernel by stage_sphere_radii
+      rnxt = ((lds_ptr)tile)[TILE_RADII + sn];  // staged once per kernel by stage_sphere_radii
+      mnxt = ((lds_ptr)tile)[TILE_MULT + sn];
     }
-    accumulate_obstacle<CL>(cfg, E, cur, cur + 3, cur + 6, rcur, false, acc);
+    accumulate_obstacle<CL>(cfg, E, cur, cur + 3, cur + 6, rcur, false, acc, mcur);
   }
 }
 
@@ -286,7 +317,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
           qdd, act,
           [&](const PandaKin<T>& K1) {
             __syncthreads();
-            publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0, cfg.jsign);  // FPJ:97-99,215-220
+            publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0, cfg.jsign, cfg.lo_merge01, cfg.lo_merge45);  // FPJ:97-99,215-220
             __syncthreads();
           });
     } else {
@@ -380,7 +411,8 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
         },
         qdd, act,
         [&](const PandaKin<T>& K1) {
-          publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0 && use_accel != 0, cfg.jsign);  // EXJ:336-339,411
+          publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0 && use_accel != 0, cfg.jsign, cfg.lo_merge01,
+                               cfg.lo_merge45);  // EXJ:336-339,411
           __syncthreads();
         });
   } else {
@@ -452,7 +484,8 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   T* sph = xch + 21 * 64;                    // [N][S][9] sphere states of the scenario
   const DevCfg<T>& cfg = *cfgp;
   const int N = cfg.n_robots;
-  const int S = LO ? 8 : cfg.n_spheres;
+  const int m01 = LO ? cfg.lo_merge01 : 0, m45 = LO ? cfg.lo_merge45 : 0;
+  const int S = LO ? 8 - m01 - m45 : cfg.n_spheres;  // distinct spheres per robot (coincident link origins merged)
   const int C = coop_chunks(N);
   const int LPR = 5 * C;  // lanes per robot
   const int lane = threadIdx.x;
@@ -516,17 +549,17 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     __syncthreads();  // the previous step's readers are done with sph / xch
     if (LO) {
       if (writer) {
-        T* dst = sph + (size_t)i * 8 * 9;
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp) {
+          T* dst = sph + ((size_t)i * S + lo_slot(sp, m01, m45)) * 9;  // merged duplicates overwrite with equal values
 #pragma unroll
           for (int k3 = 0; k3 < 3; ++k3) {
             const T x = sp < 7 ? K.o[sp < 7 ? sp : 0][k3] : K.p8[k3];
             const T v = sp < 7 ? K.vo[sp < 7 ? sp : 0][k3] : K.v8[k3];
             const T a = sp < 7 ? K.ao[sp < 7 ? sp : 0][k3] : K.a8[k3];
-            dst[sp * 9 + k3] = x;
-            dst[sp * 9 + 3 + k3] = dyn ? v : T(0);
-            dst[sp * 9 + 6 + k3] = acc_on ? cfg.jsign * a : T(0);
+            dst[k3] = x;
+            dst[3 + k3] = dyn ? v : T(0);
+            dst[6 + k3] = acc_on ? cfg.jsign * a : T(0);
           }
         }
       }
@@ -580,7 +613,8 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
         if (jr >= N) jr -= N;
         const T* src = sph + ((size_t)jr * S + sp) * 9;
         T x[3] = {src[0], src[1], src[2]}, v[3] = {src[3], src[4], src[5]}, a[3] = {src[6], src[7], src[8]};
-        accumulate_obstacle<typename LS::Collision>(cfg, E1, x, v, a, cfg.sphere_r[sp], false, a1);
+        accumulate_obstacle<typename LS::Collision>(cfg, E1, x, v, a, cfg.sphere_r[LO ? lo_sphere(sp, m01, m45) : sp], false,
+                                                    a1, LO ? T(lo_count(sp, m01, m45)) : T(1));
       }
     }
     // ---- sum the chunk partials, then give every lane of the robot all 5 points
@@ -839,6 +873,8 @@ void to_dev_leaf(const mrf_leaf_fn& s, mrf::LeafFn<T>& d) {
   d.s = (T)s.s;
 }
 
+bool is_link_origin_table(const mrf_config& c);
+
 template <typename T>
 void to_dev_cfg(const mrf_config& c, mrf::DevCfg<T>& d) {
   std::memset(&d, 0, sizeof(d));
@@ -862,6 +898,10 @@ void to_dev_cfg(const mrf_config& c, mrf::DevCfg<T>& d) {
     d.sphere_link[s] = c.sphere_link[s];
     for (int k = 0; k < 3; ++k) d.sphere_off[s][k] = (T)c.sphere_offset[s][k];
     d.sphere_r[s] = (T)c.sphere_radius[s];
+  }
+  if (is_link_origin_table(c)) {  // coincident link origins (1,2) and (5,6): one leaf with weight 2 when the radii agree
+    d.lo_merge01 = c.sphere_radius[0] == c.sphere_radius[1];
+    d.lo_merge45 = c.sphere_radius[4] == c.sphere_radius[5];
   }
   to_dev_leaf(c.collision_geometry, d.cg); to_dev_leaf(c.collision_finsler, d.cf);
   to_dev_leaf(c.plane_geometry, d.pg);     to_dev_leaf(c.plane_finsler, d.pf);

@@ -344,3 +344,33 @@ def test_baseline_config_5_eight_pandas_h50(oracle, kernel):
     assert relerr(tq.cpu().numpy(), want_q) < F64_RTOL
     assert relerr(tqd.cpu().numpy(), want_qd) < 1e-8       # 50 coupled steps of 8 robots: round-off compounds
     assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("radii", [
+    (0.08,) * 8,                                           # reference table: links 1/2 and 5/6 merged (weight 2)
+    (0.08, 0.11, 0.08, 0.08, 0.08, 0.08, 0.08, 0.08),      # links 1/2 differ -> only 5/6 merged
+    (0.08, 0.08, 0.08, 0.08, 0.06, 0.10, 0.08, 0.08),      # links 5/6 differ -> only 1/2 merged
+    (0.05, 0.06, 0.07, 0.08, 0.09, 0.10, 0.07, 0.06),      # nothing merged
+])
+def test_link_origin_table_coincident_spheres(oracle, radii, kernel):
+    """The origins of links 1/2 and 5/6 coincide (zero joint offsets): with equal radii the kernels evaluate the leaf
+    once with weight 2.  Every merge pattern must equal the oracle, which evaluates all 8 spheres."""
+    N, B = 3, 23
+    cfg = config.panda_config(n_robots=N, horizon=7)
+    cfg.kernel_select = kernel
+    cfg.goal_estimate_mask = 0b010
+    for s, r in enumerate(radii):
+        cfg.sphere_radius[s] = r
+    batch = scenarios.panda_batch(cfg, B, seed=33, x_min=0.1)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    avg, tq, tqd = h.rollout(q, qd, prm, want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
+    _, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    act = h.compute_action_coupled(q, qd, prm, use_accel=True)
+    assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
