@@ -72,6 +72,24 @@ def cfg_mounts(cfg):
     return out
 
 
+def min_barrier_coordinate(cfg, q, radius=0.08):
+    """Smallest barrier coordinate x of the collision and plane leaves per scenario for joint positions q [b,N,7]:
+    x = d/(2 r) - 1 between the ego points (link origins 3..8) of each robot and all 8 link origins of every other
+    robot, and height above the table minus r for the plane leaf."""
+    N = cfg.n_robots
+    mounts = cfg_mounts(cfg)
+    org = np.stack([link_origins(q[:, i], mounts[i]) for i in range(N)], axis=1)  # [b,N,8,3]
+    xm = np.full(len(q), np.inf)
+    for i in range(N):
+        for j in range(N):
+            if i == j:
+                continue
+            d = np.linalg.norm(org[:, i, 2:, None, :] - org[:, j, None, :, :], axis=-1)  # ego links 3..8 vs all 8
+            xm = np.minimum(xm, (d / (2 * radius) - 1).reshape(len(q), -1).min(axis=1))
+        xm = np.minimum(xm, (org[:, i, 2:, 2] - _config.Z_TABLE - radius).min(axis=1))     # plane leaf
+    return xm
+
+
 def panda_batch(cfg, n_scenarios, seed=0, x_min=0.05, q_spread=0.3, qd_spread=0.5, near_barrier=False,
                 weight_goal_0=2.0, radius=0.08):
     """Returns dict(q, qdot [7,rows], params [29,rows]) float64 numpy for `cfg` (a panda mrf_config)."""
@@ -89,16 +107,7 @@ def panda_batch(cfg, n_scenarios, seed=0, x_min=0.05, q_spread=0.3, qd_spread=0.
         idx = np.nonzero(need)[0]
         cand = p0[None] + rng.uniform(-q_spread, q_spread, (len(idx), N, 7))
         cand = np.clip(cand, lim[:, 0] + 0.1, lim[:, 1] - 0.1)
-        org = np.stack([link_origins(cand[:, i], mounts[i]) for i in range(N)], axis=1)  # [b,N,8,3]
-        ok = np.ones(len(idx), dtype=bool)
-        xm = np.full(len(idx), np.inf)
-        for i in range(N):
-            for j in range(N):
-                if i == j:
-                    continue
-                d = np.linalg.norm(org[:, i, 2:, None, :] - org[:, j, None, :, :], axis=-1)  # ego links 3..8 vs all 8
-                xm = np.minimum(xm, (d / (2 * radius) - 1).reshape(len(idx), -1).min(axis=1))
-            xm = np.minimum(xm, (org[:, i, 2:, 2] - _config.Z_TABLE - radius).min(axis=1))     # plane leaf
+        xm = min_barrier_coordinate(cfg, cand, radius)
         if near_barrier:
             ok = (xm > 0.01) & (xm < x_min)
         else:
