@@ -829,6 +829,9 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
           if (jr >= N) jr -= N;
 #pragma unroll 1
           for (int s = 0; s < S; ++s) {
+            // coincident link origins (DevCfg::lo_merge*): the second sphere of a pair is skipped, the first counts twice
+            if ((s == 1 && cfg.lo_merge01) || (s == 5 && cfg.lo_merge45)) continue;
+            const T mult = ((s == 0 && cfg.lo_merge01) || (s == 4 && cfg.lo_merge45)) ? T(2) : T(1);
             const int64_t base = ((int64_t)(jr * S + s) * 9) * n_scen + scen;
             T x[3], v[3], a[3];
 #pragma unroll
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
               v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
               a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
             }
-            accumulate_obstacle<typename LS::Collision>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc);
+            accumulate_obstacle<typename LS::Collision>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc, mult);
           }
         }
       },
