@@ -374,3 +374,26 @@ def test_link_origin_table_coincident_spheres(oracle, radii, kernel):
     _, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
     act = h.compute_action_coupled(q, qd, prm, use_accel=True)
     assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("n_robots,n_scen", [(5, 27), (16, 5)])
+def test_rollout_odd_robot_counts(oracle, n_robots, n_scen, kernel):
+    """Robot counts that do not divide the wave (5 -> 12 scenarios + 4 shadow lanes) and the ABI maximum (16)."""
+    cfg = config.panda_config(n_robots=n_robots, horizon=3)
+    if kernel == 2 and 5 * n_robots > 64:
+        pytest.skip("the cooperative kernel needs 5 lanes per robot")
+    cfg.kernel_select = kernel
+    cfg.goal_estimate_mask = 0b1010
+    batch = scenarios.panda_batch(cfg, n_scen, seed=14, x_min=0.3, q_spread=0.15)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    avg, tq, tqd = h.rollout(q, qd, prm, want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+    act = h.compute_action_coupled(q, qd, prm, use_accel=True)
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
+    _, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
