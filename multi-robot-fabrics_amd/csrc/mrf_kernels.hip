@@ -1130,9 +1130,10 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
   if (e != hipSuccess) return fail(h, MRF_E_DEVICE, std::string("config upload: ") + hipGetErrorString(e));
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
-  // measured crossover (tools/crossover.py, 3-Panda H=30): 0.36 ms up to one round of 4 waves per CU, 0.84 ms at two
-  // rounds, against a flat 0.71 ms of the row-per-lane kernel -> cooperative up to 1.5 rounds
-  h->coop_max_scen = (int64_t)cus * 6;
+  // measured crossover (tools/crossover.py, 3-Panda H=30, r01 v4): cooperative 0.35-0.42 ms up to one round of 4 waves
+  // per CU (1024 scenarios), 0.80 ms at 1.5 rounds, against a flat 0.49 ms of the row-per-lane kernel up to 8192
+  // scenarios -> cooperative up to one round
+  h->coop_max_scen = (int64_t)cus * 4;
   return MRF_OK;
 }
 

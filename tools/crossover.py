@@ -12,7 +12,7 @@ b = scenarios.panda_batch(base, 32768, seed=3)
 hs = {}
 for k in (1, 2):
     c = base.copy(); c.kernel_select = k; hs[k] = FabricHandle(c, 0)
-for B in (1, 64, 256, 1024, 2048, 4096, 8192, 16384, 32768):
+for B in (1, 64, 256, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 16384, 21504, 32768):
     out = []
     for k in (1, 2):
         h = hs[k]
