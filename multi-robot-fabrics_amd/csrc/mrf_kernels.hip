@@ -200,15 +200,16 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
     if (jr >= N) jr -= N;
     return (sp * 9) * 64 + ls * N + jr;
   };
-  T nxt[9], rnxt, mnxt;
+  // Two register buffers in ping-pong (the loop is unrolled by two) so that no buffer-to-buffer copies are needed.
+  T bufA[11], bufB[11];  // x[3], v[3], a[3], radius, multiplicity
   {
-    // The first fetch is volatile so that the optimizer cannot merge it with the in-loop fetch into one load of
+    // The first fetch is volatile so that the optimizer cannot merge it with the in-loop fetches into one load of
     // a loop-carried address at the top of the loop (which would undo the pipeline).
     lds_vptr src = (lds_vptr)(tile + address(0, 0));
 #pragma unroll
-    for (int k = 0; k < 9; ++k) nxt[k] = src[k * 64];
-    rnxt = ((lds_vptr)tile)[TILE_RADII];
-    mnxt = ((lds_vptr)tile)[TILE_MULT];
+    for (int k = 0; k < 9; ++k) bufA[k] = src[k * 64];
+    bufA[9] = ((lds_vptr)tile)[TILE_RADII];
+    bufA[10] = ((lds_vptr)tile)[TILE_MULT];
   }
   if constexpr (!CL::generic) {
     // Have the scalar loads of the leaf constants complete before the loop: the wait-count pass is static, so a
@@ -216,27 +217,29 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
     // just issued -- into every iteration.
     asm volatile("" ::"s"(cfg.jsign), "s"(cfg.cf.k), "s"(cfg.cg.k));
   }
-  int dn = 0, sn = 0;  // (other robot, slot) of the fetched-ahead sphere
-#pragma unroll 1
-  for (int m = 0; m < M; ++m) {
-    T cur[9], rcur = rnxt, mcur = mnxt;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) cur[k] = nxt[k];
-    if (m + 1 < M) {
+  int dn = 0, sn = 0;  // (other robot, slot) of the sphere fetched last
+  auto fetch_next = [&](T (&buf)[11], bool advance) {
+    if (advance) {
       if (++sn == nsp) {
         sn = 0;
         ++dn;
       }
     }
-    {
-      lds_ptr src = (lds_ptr)(tile + address(dn, sn));
+    lds_ptr src = (lds_ptr)(tile + address(dn, sn));
 #pragma unroll
-      for (int k = 0; k < 9; ++k) nxt[k] = src[k * 64];
-      rnxt = ((lds_ptr)tile)[TILE_RADII + sn];  // staged once per kernel by stage_sphere_radii
-      mnxt = ((lds_ptr)tile)[TILE_MULT + sn];
-    }
-    accumulate_obstacle<CL>(cfg, E, cur, cur + 3, cur + 6, rcur, false, acc, mcur);
+    for (int k = 0; k < 9; ++k) buf[k] = src[k * 64];
+    buf[9] = ((lds_ptr)tile)[TILE_RADII + sn];  // staged once per kernel by stage_sphere_radii
+    buf[10] = ((lds_ptr)tile)[TILE_MULT + sn];
+  };
+  int m = 0;
+#pragma unroll 1
+  for (; m + 1 < M; m += 2) {
+    fetch_next(bufB, true);
+    accumulate_obstacle<CL>(cfg, E, bufA, bufA + 3, bufA + 6, bufA[9], false, acc, bufA[10]);
+    fetch_next(bufA, m + 2 < M);  // past the end: re-reads the last sphere, never used
+    accumulate_obstacle<CL>(cfg, E, bufB, bufB + 3, bufB + 6, bufB[9], false, acc, bufB[10]);
   }
+  if (m < M) accumulate_obstacle<CL>(cfg, E, bufA, bufA + 3, bufA + 6, bufA[9], false, acc, bufA[10]);  // odd count
 }
 
 // ---------------------------------------------------------------------------- coupled joint-space rollout
