@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+F64_VECTOR_PEAK = 157.3e12 / 2   # FLOP/s: MI355X_MICROARCH.md "Peak FP32 (vector)" / 2 (f64 issues at half the f32 rate)
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6.29e12 measured copy
 
 
@@ -196,7 +197,7 @@ def main():
         units = B * N * H                                         # rollout-steps per launch
         bytes_unit = algorithmic_bytes_per_rollout_step(N, S, H, sbytes)
         achieved = units * bytes_unit / (roll_ms * 1e-3)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -205,6 +206,13 @@ def main():
             if key in tj:   # PMC counters need their own rocprofv3 passes; per-launch bytes / this run's duration
                 traffic = tj[key]["bytes_per_launch"] / (roll_ms * 1e-3) / 1e9
                 traffic_src = tj[key]
+                if "flops_per_unit" in tj[key] and args.dtype == "f64":
+                    # secondary view: the kernel is VALU-bound.  Executed f64 flops per rollout-step (PMC instruction
+                    # counters) x measured rate against the f64 vector peak (= half the guide's 157.3 TF FP32 vector
+                    # peak: one v_fma_f64 per SIMD every 4 cycles)
+                    tf = units * tj[key]["flops_per_unit"] / (roll_ms * 1e-3) / 1e12
+                    valu = {"achieved": tf, "peak": F64_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf * 1e12 / F64_VECTOR_PEAK,
+                            "flops_per_unit": tj[key]["flops_per_unit"]}
         control_rate = world * B * args.steps / elapsed
         out = {
             "metric": "planner control-steps/s (rollout + per-robot compute_action), 3-Panda RF-CV H=30"
@@ -220,7 +228,7 @@ def main():
             "rollout_kernel_ms": roll_ms,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "valu_f64": valu,
                          "kernel": "k_rollout_panda", "units_per_launch": units, "bytes_per_unit": bytes_unit,
                          "note": "algorithmic bytes of the step-wise exchanged formulation; the fused kernel keeps "
                                  "the exchange on chip, so it is VALU-bound and `traffic` is far below `achieved`"},
