@@ -207,6 +207,7 @@ typedef struct mrf_deadlock_config { /* thresholds of deadlock_prevention.py:12-
   int32_t grasp_timeout;       /* DP:109  400 ... by setting time_deadlock_out to this                         */
 } mrf_deadlock_config;
 void mrf_default_deadlock_config(mrf_deadlock_config* c, int32_t point_mass);
+int64_t mrf_deadlock_config_sizeof(void); /* sizeof(mrf_deadlock_config) as compiled, for FFI layout checks */
 
 /* per-scenario deadlock state, int32 dl_state[MRF_DL_NSTATE][n_scenarios] + scalar dl_goal[3][n_scenarios]
  * (= the attributes of the reference's deadlockprevention object that its logic reads back, DP:9-34) */

@@ -78,7 +78,7 @@ EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
     "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
     "mrf_fk_spheres", "mrf_step_predict", "mrf_step_action",
-    "mrf_default_deadlock_config", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
+    "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
 ]
 
@@ -147,6 +147,8 @@ def load_library(path=None):
     dlp = C.POINTER(DeadlockConfig)
     lib.mrf_default_deadlock_config.argtypes = [dlp, i32]
     lib.mrf_default_deadlock_config.restype = None
+    lib.mrf_deadlock_config_sizeof.argtypes = []
+    lib.mrf_deadlock_config_sizeof.restype = C.c_int64
     lib.mrf_deadlock_init.argtypes = [vp, i64, vp, vp, vp]
     lib.mrf_deadlock_init.restype = C.c_int
     lib.mrf_control_prepare.argtypes = [vp, i64, vp, vp, vp, vp, i32, vp, vp]
@@ -162,6 +164,8 @@ def load_library(path=None):
         raise MrfLibraryError(f"ABI mismatch: library {lib.mrf_abi_version()} != python {MRF_ABI_VERSION}")
     if lib.mrf_config_sizeof() != C.sizeof(Config):
         raise MrfLibraryError(f"mrf_config size mismatch: C {lib.mrf_config_sizeof()} != ctypes {C.sizeof(Config)}")
+    if lib.mrf_deadlock_config_sizeof() != C.sizeof(DeadlockConfig):
+        raise MrfLibraryError("mrf_deadlock_config size mismatch")
     if path is None:
         _lib = lib
     return lib

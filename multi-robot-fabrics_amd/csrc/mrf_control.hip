@@ -215,6 +215,8 @@ int need_panda_vel(mrf_handle* h, const char* what) {
 
 extern "C" {
 
+int64_t mrf_deadlock_config_sizeof(void) { return (int64_t)sizeof(mrf_deadlock_config); }
+
 void mrf_default_deadlock_config(mrf_deadlock_config* c, int32_t point_mass) {
   std::memset(c, 0, sizeof(*c));
   c->avg_vel_constant = point_mass ? 0.03 : 0.16;

@@ -249,3 +249,25 @@ def test_deadlock_checking_known_answers():
     g3, w3, t3 = dp2.deadlock_checking(x + [np.array([2.0, 2.0, 1.0])], list(goals) + [np.zeros(3)], [2.0] * 3, time_step=5,
                                        time_deadlock_out=1000, avg_sum=0.0, state_machine_robots=[0, 0, 0])
     assert w3 == [2.0] * 3 and t3 == 1000
+
+
+def test_deadlock_config_defaults_and_null_handles():
+    """Host-only parts of the control-step ABI: the thresholds of deadlock_prevention.py:12-27 (+ literals of :50-118)
+    and argument checking without a device."""
+    lib = abi.load_library()
+    assert lib.mrf_deadlock_config_sizeof() == C.sizeof(abi.DeadlockConfig)
+    c = abi.DeadlockConfig()
+    lib.mrf_default_deadlock_config(C.byref(c), 0)
+    assert (c.avg_vel_constant, c.dist_constant, c.goal_weight_follower, c.goal_weight_leader, c.time_wait,
+            c.nr_goal_scale) == (0.16, 0.0, 2.0, 3.0, 300, 2.0)
+    assert (c.ee_distance, c.follower_offset, c.min_goal_norm, c.z_floor, c.min_time_step, c.grasp_state,
+            c.grasp_timeout) == (0.35, 0.3, 0.05, 0.1, 10, 2, 400)
+    lib.mrf_default_deadlock_config(C.byref(c), 1)
+    assert (c.avg_vel_constant, c.dist_constant, c.goal_weight_follower, c.goal_weight_leader, c.time_wait,
+            c.nr_goal_scale) == (0.03, 1.0, 10.0, 1.0, 50, 100.0)
+    vl = (C.c_double * 7)(*[1.0] * 7)
+    assert lib.mrf_deadlock_init(None, 4, None, None, None) == -1
+    assert lib.mrf_control_prepare(None, 4, None, None, None, None, 1, None, None) == -1
+    assert lib.mrf_deadlock_step(None, 4, C.byref(c), -1, None, None, None, None, None, None, None) == -1
+    assert lib.mrf_apply_action(None, 4, None, None, None, vl, -1.0, None) == -1
+    assert lib.mrf_episode_run(None, None, 4, 1, None, 0, vl, -1.0, *([None] * 10), 0, None) == -1
