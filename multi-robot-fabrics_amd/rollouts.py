@@ -11,6 +11,7 @@ the per-step entry points launch one persistent kernel.  The *_batch methods are
 many scenarios at once (device tensors in, device tensors out).
 """
 import numpy as np
+import torch
 
 from . import abi
 from . import config as _config
@@ -138,6 +139,31 @@ class ForwardFabricsPlanner:
             qdN["robot_%d" % i] = [tqd[:, :, i].T.copy()]
             qddN["robot_%d" % i] = [np.zeros_like(tq[:, :, i].T)]
         return qN, qdN, qddN
+
+    def rollouts_numerical_obstacles(self, inputs_action):
+        """-> (x_N, v_N, a_N): dicts 'robot_i' -> list over the H steps of ndarray(3, 8*(N-1)): the spheres of the
+        other robots as robot i sees them at step k (FPJ:425-512 evaluating the graph outputs of FPJ:211-225,250-253):
+        positions after the step's position update, v = J qdot and a = jdot_sign * Jdot qdot with the velocities the
+        robots had BEFORE this step's actions; zeros for static fabrics (FPJ:215-217)."""
+        h = self._handle
+        if h is None:
+            raise RuntimeError("call forward_multi_fabrics_symbolic() first")
+        q, qd, prm = h.upload(*self._rows(inputs_action))
+        _, tq, tqd = h.rollout(q, qd, prm, want_traj=True)                      # [H, 7, N]
+        H, N, S = self.N_horizon, self.nr_robots, h.cfg.n_spheres
+        qd_before = torch.cat([qd[None], tqd[:-1]], dim=0)                       # velocities entering step k
+        flat = lambda t: t.permute(1, 0, 2).reshape(7, H * N).contiguous()       # row = k*N + robot
+        x, v, a = (t.cpu().numpy().reshape(S, 3, H, N) for t in h.fk_spheres(flat(tq), flat(qd_before)))
+        dyn = bool(h.cfg.dynamic)
+        xN, vN, aN = ({"robot_%d" % i: [] for i in range(N)} for _ in range(3))
+        for i in range(N):
+            others = [j for j in range(N) if j != i]
+            for k in range(H):
+                xs = np.concatenate([x[:, :, k, j].T for j in others], axis=1)   # (3, S*(N-1))
+                xN["robot_%d" % i].append(xs)
+                vN["robot_%d" % i].append(np.concatenate([v[:, :, k, j].T for j in others], axis=1) if dyn else np.zeros_like(xs))
+                aN["robot_%d" % i].append(np.concatenate([a[:, :, k, j].T for j in others], axis=1) if dyn else np.zeros_like(xs))
+        return xN, vN, aN
 
     def compute_velocity_average(self, q_dot_robots_N):
         """FPJ:102-116 on numeric trajectories: sum of squares / (H * dof) per robot."""

@@ -149,6 +149,18 @@ def test_forward_fabrics_planner(oracle, n_robots, estimate):
         assert np.abs(qdN[f"robot_{i}"][0] - want_qd[:, :, i].T).max() < 1e-9
         assert not qddN[f"robot_{i}"][0].any()
     assert np.allclose(fp.compute_velocity_average(qdN), want_avg, rtol=1e-9)
+    # per-step obstacle outputs (ROLLOUTS_PLOTTING, FPJ:250-253,425-512): robot i sees the other robots' 8 link spheres
+    xN, vN, aN = fp.rollouts_numerical_obstacles(inputs_action)
+    S = cfg.n_spheres
+    for k in (0, 3, 5):
+        qd_before = b["qdot"] if k == 0 else want_qd[k - 1]
+        sx, sv, sa = oracle.fk_spheres(cfg, want_q[k], qd_before)               # [S,3,N]
+        for i in range(n_robots):
+            others = [j for j in range(n_robots) if j != i]
+            assert xN[f"robot_{i}"][k].shape == (3, S * (n_robots - 1))
+            assert np.abs(xN[f"robot_{i}"][k] - np.concatenate([sx[:, :, j].T for j in others], axis=1)).max() < 1e-9
+            assert np.abs(vN[f"robot_{i}"][k] - np.concatenate([sv[:, :, j].T for j in others], axis=1)).max() < 1e-9
+            assert np.abs(aN[f"robot_{i}"][k] - np.concatenate([sa[:, :, j].T for j in others], axis=1)).max() < 1e-9
 
 
 def test_fabrics_rollouts_cartesian(oracle):
