@@ -335,6 +335,52 @@ class FabricsRollouts:
         qdd = np.diff(np.concatenate([np.asarray(self._unpack(arguments)[1])[:, None], tqd], axis=1), axis=1) / self.dt
         return tq, tqd, qdd
 
+    # -- the numeric twin of the rollout (FPC:132-273): one planner.compute_action per horizon step -------------------
+    def get_action(self, planner, pos, vel, x_obsts, x_obsts_dyn, x_goals, weight_goals):
+        """planner.compute_action with this rollout's constants filled in (FPC:132-191; the `ring` and the plain
+        branch pass the same arguments)."""
+        x_goals, weight_goals = list(x_goals), list(weight_goals)
+        for _ in range(3 - self.nr_goals):        # FPC:143-147: pad to three sub-goals
+            x_goals.append(0)
+            weight_goals.append(0)
+        return planner.compute_action(
+            q=pos, qdot=vel, x_obsts=x_obsts, radius_obsts=self.radius_obsts, angle_goal_1=self.rotation_matrix_panda,
+            x_goal_0=x_goals[0], x_goal_1=x_goals[1], x_goal_2=x_goals[2], weight_goal_0=weight_goals[0],
+            weight_goal_1=weight_goals[1], weight_goal_2=weight_goals[2], x_obsts_dynamic=x_obsts_dyn,
+            xdot_obsts_dynamic=self.v_obsts_dyn, xddot_obsts_dynamic=[np.array([0.0, 0.0, 0.0])] * self.nr_obsts_dyn,
+            radius_obsts_dynamic=self.radius_obsts_dyn, radius_body_panda_links=self.radius_body_panda_links,
+            radius_body_panda_hand=np.array([0.08]), constraint_0=self.constraints)
+
+    def get_x_obsts_dyn_N(self, x_obsts_dyn):
+        """FPC:195-216: obstacle positions at k = 0..N as (3, n) arrays, and per step k = 0..N-1 as lists of 3-vectors."""
+        x0 = np.stack([np.asarray(p, dtype=float).reshape(-1)[:3] for p in x_obsts_dyn]).transpose()
+        v = np.stack([np.asarray(p, dtype=float).reshape(-1)[:3] for p in self.v_obsts_dyn]).transpose()
+        arrays = [x0 + k * self.Ts * v for k in range(self.N + 1)]
+        lists = [[arrays[k][:, j].copy() for j in range(self.nr_obsts_dyn)] for k in range(self.N)]
+        return arrays, lists
+
+    def forward_fabrics(self, planner, pos_k, vel_k, ob_robot=None, goal=None, x_obsts_dyn_0=None, x_goals_struct=None,
+                        weight_goals_struct=None, x_obsts=()):
+        """FPC:218-273: numeric rollout, action-then-step, obstacles at constant velocity.  Returns lists over the
+        horizon of q, q_dot, q_ddot (the last one empty in mode 'vel').  Goals and obstacle positions must be passed
+        explicitly (the reference can also pull them out of the simulator's observation `ob_robot`)."""
+        if x_goals_struct is None or weight_goals_struct is None or (self.nr_obsts_dyn > 0 and x_obsts_dyn_0 is None):
+            raise NotImplementedError("pass x_obsts_dyn_0, x_goals_struct and weight_goals_struct (no simulator observation here)")
+        steps = self.get_x_obsts_dyn_N(x_obsts_dyn_0)[1] if self.nr_obsts_dyn > 0 else [[] for _ in range(self.N)]
+        pos_k, vel_k = np.asarray(pos_k, dtype=float).copy(), np.asarray(vel_k, dtype=float).copy()
+        q_stacked, qdot_stacked, qddot_stacked = [], [], []
+        for k in range(self.N):
+            u_k = self.get_action(planner, pos_k, vel_k, x_obsts=list(x_obsts), x_obsts_dyn=steps[k],
+                                  x_goals=list(x_goals_struct.values()), weight_goals=list(weight_goals_struct.values()))
+            pos_k, vel_k = self.system_step(pos_k, vel_k, u_k, dt=self.dt, fabrics_mode=self.fabrics_mode)
+            if self.fabrics_mode == "acc":
+                qddot_stacked.append(np.array(u_k, copy=True))
+                qdot_stacked.append(vel_k.copy())
+            else:
+                qdot_stacked.append(np.array(u_k, copy=True))
+            q_stacked.append(pos_k.copy())
+        return q_stacked, qdot_stacked, qddot_stacked
+
     def x_obsts_dyn_numerical(self, pos_obsts_dyn):
         """Obstacle positions after each step, x += dt*v (FPC:448-453,491-505): list over k of (3, n_obst) arrays."""
         x = np.stack([np.asarray(p, dtype=float).reshape(-1)[:3] for p in pos_obsts_dyn]) if len(pos_obsts_dyn) else np.zeros((0, 3))

@@ -196,6 +196,15 @@ def test_fabrics_rollouts_cartesian(oracle):
     assert np.abs(qN - want_q[:, :, 0].T).max() < 1e-9 and np.abs(qdN - want_qd[:, :, 0].T).max() < 1e-9
     xs = fr.x_obsts_dyn_numerical(x_dyn)
     assert len(xs) == 5 and xs[0].shape == (3, 8)
+    # the numeric twin (EXC:386-393, FPC:218-273): one compute_action per step == the fused rollout kernel
+    fr.reset_v_obsts_dyn(v_dyn)
+    arrays, lists = fr.get_x_obsts_dyn_N(x_dyn)
+    assert len(arrays) == 6 and arrays[0].shape == (3, 8) and len(lists) == 5 and len(lists[0]) == 8
+    assert np.allclose(arrays[3], np.array(x_dyn).T + 3 * params.dt * np.array(v_dyn).T, atol=1e-15)
+    qs, qds, qdds = fr.forward_fabrics(planner=planner, pos_k=b["q"][:, i], vel_k=b["qdot"][:, i], x_obsts_dyn_0=x_dyn,
+                                       x_goals_struct=x_goals, weight_goals_struct=weight_goals)
+    assert len(qs) == 5 and qdds == []
+    assert np.abs(np.array(qs).T - qN).max() < 1e-9 and np.abs(np.array(qds).T - qdN).max() < 1e-9
 
 
 def test_utils_kinematics_functions(oracle):
