@@ -397,3 +397,60 @@ def test_rollout_odd_robot_counts(oracle, n_robots, n_scen, kernel):
     ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
     _, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
     assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_planner_configurations(oracle, seed):
+    """Randomised planner definitions (leaf families / exponents / gates through the string front-end, every named
+    constant of mrf_config, mode, number of goals, plane/limit switches): the generic kernel instantiations against the
+    oracle -- compute_action with explicit obstacle arrays, the coupled action and the rollout."""
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.integers(2, 4))
+    cfg = config.panda_config(n_robots=N, horizon=4, dynamic=int(rng.integers(0, 2)))
+    gate = lambda: rng.choice(["", " * (1 - ca.heaviside(xdot))", " * (-0.5 * (ca.sign(xdot) - 1))"])
+    def pow_leaf(sign, kmax, pmax):
+        return f"{sign}{rng.uniform(0.05, kmax):.4f} / (x ** {int(rng.integers(1, pmax + 1))}){gate()} * xdot ** 2"
+    def logistic(sign):
+        return f"{sign}{rng.uniform(1, 12):.3f}*(1/(1+{rng.uniform(0.5, 2):.3f}*ca.exp(-{rng.uniform(2, 12):.3f}*x))-1) * (xdot**2)"
+    config.set_strings(cfg,
+                       collision_geometry=pow_leaf("-", 1.0, 5) if rng.random() < 0.7 else logistic(""),
+                       collision_finsler=pow_leaf("", 0.1, 5),
+                       geometry_plane_constraint=logistic("") if rng.random() < 0.5 else pow_leaf("-", 1.0, 3),
+                       finsler_plane_constraint=pow_leaf("", 0.5, 3),
+                       limit_geometry=pow_leaf("-", 0.5, 3), limit_finsler=pow_leaf("", 0.5, 3))
+    cfg.base_mass = rng.uniform(0.05, 1.0)
+    cfg.attr_k, cfg.attr_alpha = rng.uniform(1, 10), rng.uniform(2, 20)
+    cfg.attr_mu, cfg.attr_ml, cfg.attr_a = rng.uniform(1, 3), rng.uniform(0.1, 0.9), rng.uniform(0.2, 2)
+    cfg.beta_a, cfg.beta_r, cfg.beta_b, cfg.beta_s = rng.uniform(0.1, 2), rng.uniform(0.01, 0.2), rng.uniform(1, 10), rng.uniform(0, 0.1)
+    cfg.eta_a, cfg.eta_s = rng.uniform(0.1, 1), rng.uniform(0.1, 1)
+    cfg.eps = 10.0 ** rng.uniform(-8, -4)
+    cfg.goal_estimate_T = rng.uniform(0.05, 0.5)
+    cfg.goal_estimate_mask = int(rng.integers(0, 1 << N))
+    cfg.n_goals = int(rng.integers(0, 4))
+    cfg.n_planes = int(rng.integers(0, 2))
+    cfg.use_limits = int(rng.integers(0, 2))
+    cfg.plane_abs = int(rng.integers(0, 2))
+    cfg.zero_small_action = int(rng.integers(0, 2))
+    cfg.dt = rng.uniform(0.002, 0.02)
+    if rng.random() < 0.5:
+        links, offs = config.sphere_offsets_per_link(int(rng.integers(1, 3)))
+        config.set_spheres(cfg, links, offs, radii=rng.uniform(0.05, 0.1, len(links)))
+    batch = scenarios.panda_batch(cfg, 19, seed=seed, x_min=0.25)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    # rollout (mode 'vel' only) and coupled action
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    avg, tq, tqd = h.rollout(q, qd, prm, want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL, "rollout"
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv if cfg.dynamic else None, sa if cfg.dynamic else None)
+    for mode in (abi.MODE_VEL, abi.MODE_ACC):
+        c2 = cfg.copy()
+        c2.mode = mode
+        h2 = FabricHandle(c2, 0)
+        want_qdd, want_act = oracle.compute_action(c2, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+        act, qdd = h2.compute_action(q, qd, prm, h2.tensor(ox), h2.tensor(ov), h2.tensor(oa), h2.tensor(orad), want_qddot=True)
+        assert relerr(qdd.cpu().numpy(), want_qdd) < F64_RTOL, "compute_action qddot"
+        assert relerr(act.cpu().numpy(), want_act) < F64_RTOL, "compute_action action"
+        act_c = h2.compute_action_coupled(q, qd, prm, use_accel=True)
+        assert relerr(act_c.cpu().numpy(), want_act) < F64_RTOL, "coupled action"
