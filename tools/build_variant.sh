@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build a kernel variant into ab/lib<name>.so for same-box A/B timing:
-#   tools/build_variant.sh <name> [git-rev] [extra hipcc flags...]
+#   tools/build_variant.sh <name> [git-rev|-] [extra hipcc flags for the solve kernels...]   (KERNEL_FLAGS= overrides -ffast-math)
 #   MRF_HIP_LIB=ab/lib<name>.so python3 tools/prof_rollout.py ...
 # With a git revision the csrc/ and include/ trees of that revision are compiled (from a temp copy).
 set -e
@@ -12,6 +12,14 @@ if [ -n "$rev" ] && [ "$rev" != "-" ]; then
   src=$(mktemp -d)
   git archive "$rev" multi-robot-fabrics_amd/csrc include | tar -x -C "$src"
 fi
-srcs="$src/multi-robot-fabrics_amd/csrc/mrf_kernels.hip"
-[ -f "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" ] && srcs="$srcs $src/multi-robot-fabrics_amd/csrc/mrf_control.hip"
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" -o ab/lib$name.so $srcs
+# same per-file flags as __graft_entry__.build(): the solve kernels with -ffast-math, the control-step unit without
+tmp=$(mktemp -d)
+hip="/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC"
+$hip ${KERNEL_FLAGS--ffast-math} "$@" -c -o $tmp/k.o "$src/multi-robot-fabrics_amd/csrc/mrf_kernels.hip" &
+objs="$tmp/k.o"
+if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" ]; then
+  $hip -c -o $tmp/c.o "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" &
+  objs="$objs $tmp/c.o"
+fi
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/lib$name.so $objs

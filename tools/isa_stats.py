@@ -44,7 +44,7 @@ def main():
     if not os.path.exists(ASM) or os.path.getmtime(ASM) < max(
             os.path.getmtime(SRC), os.path.getmtime(os.path.join(os.path.dirname(SRC), "mrf_device.hpp"))):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17",
-                               "--cuda-device-only", "-S", "-DMRF_ISA_MARKS", "-o", ASM, SRC], stderr=subprocess.DEVNULL)
+                               "-ffast-math", "--cuda-device-only", "-S", "-DMRF_ISA_MARKS", "-o", ASM, SRC], stderr=subprocess.DEVNULL)
     lines = open(ASM).read().split("\n")
     starts = [(i, m.group(1)) for i, l in enumerate(lines) if (m := re.match(r"^(_Z\w+):", l))]
     names = subprocess.run(["c++filt"], input="\n".join(n for _, n in starts), capture_output=True, text=True).stdout.split("\n")
