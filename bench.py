@@ -153,6 +153,7 @@ def main():
 
     if args.shard == "robots":
         from multi_robot_fabrics_amd.sharded import ShardedRollout
+        args.scenarios = B
         result = ShardedRollout.bench(cfg_roll, batch, args, rank, world, local_rank)
         if rank == 0:
             print(json.dumps(result))

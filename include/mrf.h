@@ -173,9 +173,13 @@ int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot,
  *   mrf_step_action  : fabric solve of the owned robots against all other robots' spheres;
  *                      qdot := action; sumsq += |qdot|^2
  * Owned rows are [n_scenarios][robot_count] with robot index robot_first + (row % robot_count).
- *   sph_own  [robot_count][S][9][n_scenarios]   (x,v,a interleaved as 9 components)
- *   sph_all  [n_robots  ][S][9][n_scenarios]
+ *   sph_own  [robot_count][SX][9][n_scenarios]   (x,v,a interleaved as 9 components)
+ *   sph_all  [n_robots  ][SX][9][n_scenarios]
+ * SX = mrf_exchange_spheres(h): cfg.n_spheres, minus one for each pair of coincident spheres of the link-origin table
+ * (the origins of links 1/2 and of links 5/6 are the same point; with equal radii only one of them travels and the
+ * receiver counts it twice) -- 6 instead of 8 for the reference's rollout table.
  */
+int32_t mrf_exchange_spheres(const mrf_handle* h);
 int mrf_step_predict(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, void* q_io,
                      const void* qdot, void* sph_own, void* stream);
 int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,

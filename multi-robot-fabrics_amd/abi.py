@@ -77,7 +77,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
 EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
     "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
-    "mrf_fk_spheres", "mrf_step_predict", "mrf_step_action",
+    "mrf_fk_spheres", "mrf_exchange_spheres", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
 ]
@@ -140,6 +140,8 @@ def load_library(path=None):
     lib.mrf_rollout_cartesian.restype = C.c_int
     lib.mrf_fk_spheres.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.mrf_fk_spheres.restype = C.c_int
+    lib.mrf_exchange_spheres.argtypes = [vp]
+    lib.mrf_exchange_spheres.restype = i32
     lib.mrf_step_predict.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
     lib.mrf_step_predict.restype = C.c_int
     lib.mrf_step_action.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]

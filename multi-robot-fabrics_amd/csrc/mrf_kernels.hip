@@ -785,7 +785,8 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
     xch[(3 * j + 2) * 64 + lane] = qdj;
   }
   __syncthreads();
-  const int S = cfg.n_spheres;
+  const int m01 = cfg.lo_merge01, m45 = cfg.lo_merge45;
+  const int SX = cfg.n_spheres - m01 - m45;  // == mrf_exchange_spheres()
   panda_walk_spheres<false, T>(
       cfg, cfg.mount[robot_first + lr],
       [&](int j, T& c, T& s, T& qdj) {
@@ -794,8 +795,9 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
         qdj = xch[(3 * j + 2) * 64 + lane];
       },
       [&](int s, const T* x, const T* v, const T* a) {
-        if (!active) return;
-        const int64_t base = ((int64_t)(lr * S + s) * 9) * n_scen + scen;
+        // coincident link origins (DevCfg::lo_merge*) are exchanged once: S - merges slots per robot
+        if (!active || (s == 1 && m01) || (s == 5 && m45)) return;
+        const int64_t base = ((int64_t)(lr * SX + lo_slot(s, m01, m45)) * 9) * n_scen + scen;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           sph_own[base + (int64_t)c * n_scen] = x[c];
@@ -821,7 +823,9 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
   PandaState<T> R;
   load_state(rows, r, q, (const T*)qd_io, R);
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
-  const int N = cfg.n_robots, S = cfg.n_spheres;
+  const int N = cfg.n_robots;
+  const int m01 = cfg.lo_merge01, m45 = cfg.lo_merge45;
+  const int SX = cfg.n_spheres - m01 - m45;  // == mrf_exchange_spheres()
   T qdd[7], act[7];
   panda_solve_row<LS, true>(
       cfg, cfg.mount[me], R, P,
@@ -831,11 +835,11 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
           int jr = me + d;
           if (jr >= N) jr -= N;
 #pragma unroll 1
-          for (int s = 0; s < S; ++s) {
-            // coincident link origins (DevCfg::lo_merge*): the second sphere of a pair is skipped, the first counts twice
-            if ((s == 1 && cfg.lo_merge01) || (s == 5 && cfg.lo_merge45)) continue;
-            const T mult = ((s == 0 && cfg.lo_merge01) || (s == 4 && cfg.lo_merge45)) ? T(2) : T(1);
-            const int64_t base = ((int64_t)(jr * S + s) * 9) * n_scen + scen;
+          for (int slot = 0; slot < SX; ++slot) {
+            // exchanged slots: coincident link origins (DevCfg::lo_merge*) arrive once and count twice
+            const int s = lo_sphere(slot, m01, m45);
+            const T mult = T(lo_count(slot, m01, m45));
+            const int64_t base = ((int64_t)(jr * SX + slot) * 9) * n_scen + scen;
             T x[3], v[3], a[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1258,6 +1262,14 @@ int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot,
     return launch(h, mrf::k_fk_spheres_panda<T>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
                   (const T*)qdot, (T*)x_out, (T*)v_out, (T*)a_out);
   });
+}
+
+int32_t mrf_exchange_spheres(const mrf_handle* h) {
+  if (!h) return 0;
+  const mrf_config& c = h->cfg;
+  int n = c.n_spheres;
+  if (is_link_origin_table(c)) n -= (c.sphere_radius[0] == c.sphere_radius[1]) + (c.sphere_radius[4] == c.sphere_radius[5]);
+  return n;
 }
 
 int mrf_step_predict(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, void* q_io,

@@ -167,9 +167,14 @@ class FabricHandle:
         self._check(rc)
         return x, v, a
 
+    @property
+    def exchange_spheres(self):
+        """Spheres per robot in the sharded exchange buffers (coincident link origins travel once)."""
+        return int(self.lib.mrf_exchange_spheres(self._h))
+
     def step_predict(self, n_scen, robot_first, robot_count, q_io, qdot, sph_own, stream=None):
         rows = n_scen * robot_count
-        S = self.cfg.n_spheres
+        S = self.exchange_spheres
         rc = self.lib.mrf_step_predict(self._h, n_scen, robot_first, robot_count,
                                        self._arg(q_io, (self.dof, rows), "q_io"),
                                        self._arg(qdot, (self.dof, rows), "qdot"),
@@ -179,7 +184,7 @@ class FabricHandle:
 
     def step_action(self, n_scen, robot_first, robot_count, q, qdot_io, params, sph_all, sumsq_io, stream=None):
         rows = n_scen * robot_count
-        S, N = self.cfg.n_spheres, self.cfg.n_robots
+        S, N = self.exchange_spheres, self.cfg.n_robots
         rc = self.lib.mrf_step_action(self._h, n_scen, robot_first, robot_count, self._arg(q, (self.dof, rows), "q"),
                                       self._arg(qdot_io, (self.dof, rows), "qdot_io"),
                                       self._arg(params, (abi.NPARAM, rows), "params"),

@@ -8,7 +8,8 @@ predicted collision-sphere states after every rollout step (the excha
         all_gather         over the G ranks of the replica (RCCL over xGMI on GPUs; gloo in the CPU tests)
         mrf_step_action    fabric solve of the owned robots against everybody else's spheres; qdot := action
 
-The collective moves S*9*B scalars per owned robot per step (B=1: 576 B in f64), so at small B it is latency-bound;
+The collective moves SX*9*B scalars per owned robot per step, SX = mrf_exchange_spheres (6 for the reference's 8
+link-origin spheres: the origins of links 1/2 and 5/6 coincide and travel once; B=1: 432 B in f64), so at small B it is latency-bound;
 batching scenarios is what makes the link time matter.  The compute backend is injectable so that the
 partitioning / gather logic is testable on CPU ranks (tests pass an oracle-backed stand-in); the default backend
 is the HIP kernels and there is no CPU fallback.
@@ -43,6 +44,7 @@ class HipStepBackend:
         from .runtime import FabricHandle
         self.h = FabricHandle(cfg, device_index)
         self.dtype, self.device = self.h.dtype, self.h.device
+        self.exchange_spheres = self.h.exchange_spheres      # 6 of the 8 link-origin spheres: two pairs coincide
 
     def predict(self, n_scen, first, count, q_io, qd, sph_own):
         self.h.step_predict(n_scen, first, count, q_io, qd, sph_own)
@@ -64,6 +66,7 @@ class ShardedRollout:
         self.uniform = all(c == self.cnt_max for _, c in self.parts)
         self.backend = backend if backend is not None else HipStepBackend(cfg, device_index)
         self.dtype, self.device = self.backend.dtype, self.backend.device
+        self.S = getattr(self.backend, "exchange_spheres", cfg.n_spheres)   # spheres per robot on the wire
         self.group = None
         if world > 1:
             # one communicator per replica; every rank must take part in every new_group call
@@ -132,7 +135,7 @@ class ShardedRollout:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert torch.isfinite(avg).all()
-        N, H, S = cfg.n_robots, cfg.horizon, cfg.n_spheres
+        N, H, S = cfg.n_robots, cfg.horizon, sr.S
         sb = 8 if cfg.scalar == abi.F64 else 4
         rate = sr.D * B * args.steps / elapsed
         return {
@@ -142,7 +145,8 @@ class ShardedRollout:
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{N}-Panda RF-CV H={H} coupled rollout only", "scenarios_per_replica": B,
                        "robot_group_ranks": sr.G, "replicas": sr.D, "robots_per_rank": [c for _, c in sr.parts],
-                       "sharding": "robots (all-gather of S*9*B sphere scalars per robot per rollout step)"},
+                       "sharding": "robots (all-gather of SX*9*B sphere scalars per robot per rollout step)",
+                       "exchanged_spheres_per_robot": S},
             "rollout_steps_per_s": rate * N * H,
             "allgather_bytes_per_rank_per_step": sr.cnt_max * S * 9 * B * sb,
         }

@@ -210,25 +210,29 @@ def test_fk_spheres_with_offsets(oracle):
     assert v_none is None and torch.equal(x_only, x)
 
 
-@pytest.mark.parametrize("robot_first,robot_count", [(0, 3), (1, 1), (1, 2)])
-def test_sharded_step_matches_fused_rollout(oracle, robot_first, robot_count):
+@pytest.mark.parametrize("robot_first,robot_count,r1", [(0, 3, 0.08), (1, 1, 0.08), (1, 2, 0.08), (1, 2, 0.11)])
+def test_sharded_step_matches_fused_rollout(oracle, robot_first, robot_count, r1):
     """predict -> (gather) -> action for a subset of robots reproduces the fused rollout's trajectory."""
     N, H, B = 3, 7, 19
     cfg = config.panda_config(n_robots=N, horizon=H)
+    cfg.sphere_radius[1] = r1        # != sphere_radius[0]: the link-1/2 pair is no longer merged
     batch = scenarios.panda_batch(cfg, B, seed=51, x_min=0.08)
     want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
     h = FabricHandle(cfg, 0)
     S = cfg.n_spheres
+    SX = h.exchange_spheres          # the coincident origins of links 1/2 and 5/6 travel once
+    keep = [0, 2, 3, 4, 6, 7] if r1 == 0.08 else [0, 1, 2, 3, 4, 6, 7]
+    assert SX == len(keep)
     sel = np.array([s * N + robot_first + l for s in range(B) for l in range(robot_count)])
     q = h.tensor(batch["q"][:, sel]); qd = h.tensor(batch["qdot"][:, sel]); prm = h.tensor(batch["params"][:, sel])
     sumsq = torch.zeros(B * robot_count, dtype=torch.float64, device="cuda")
     for k in range(H):
-        sph_own = torch.empty((robot_count, S, 9, B), dtype=torch.float64, device="cuda")
+        sph_own = torch.empty((robot_count, SX, 9, B), dtype=torch.float64, device="cuda")
         h.step_predict(B, robot_first, robot_count, q, qd, sph_own)
         # spheres of the robots this "rank" does not own come from the oracle trajectory (stand-in for the all-gather)
         qk, qdk = want_q[k], (want_qd[k - 1] if k else batch["qdot"])
         sx, sv, sa = oracle.fk_spheres(cfg, qk, qdk)
-        sph_all = np.concatenate([sx, sv, sa], axis=1).reshape(S, 9, B, N).transpose(3, 0, 1, 2).copy()
+        sph_all = np.concatenate([sx, sv, sa], axis=1).reshape(S, 9, B, N).transpose(3, 0, 1, 2)[:, keep].copy()
         sph_all_t = h.tensor(sph_all)
         assert relerr(sph_own.cpu().numpy(), sph_all[robot_first:robot_first + robot_count]) < 1e-9
         sph_all_t[robot_first:robot_first + robot_count] = sph_own
