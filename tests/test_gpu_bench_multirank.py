@@ -1,0 +1,30 @@
+"""bench.py's world > 1 protocol (per-rank batches, barrier + synchronize around the timed region, MAX over ranks,
+one JSON line from rank 0) exercised with two ranks sharing the single GPU of the test box (MRF_BENCH_SHARE_GPU=1:
+gloo instead of RCCL for the barrier and the all-reduce of the elapsed time)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_one_gpu_scenario_sharding():
+    env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--scenarios", "4032"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["config"]["scenarios_per_gpu"] == 4032
+    # whole-job aggregate: both ranks' scenarios over the slowest rank's time
+    assert abs(r["value"] - 2 * 4032 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-9
+    assert "cpu_baseline" not in r and "single_scenario" not in r
+    assert r["roofline"]["bound"] == "hbm" and r["roofline"]["frac"] > 0

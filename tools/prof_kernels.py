@@ -62,15 +62,18 @@ report("k_rollout_panda (H=30)", timed(lambda: h.rollout(q, qd, prm)), rows * H,
        "rollout_steps")
 report("k_rollout_cart_panda (H=30, M=16)", timed(lambda: h.rollout_cartesian(q, qd, prm, ox, ov, oa, orad), iters=4), rows * H,
        sb * (43 + 10 * M * H + 14) / H, "rollout_steps")
+report("k_rollout_cart_panda (H=30, M=16, obst_a = NULL)", timed(lambda: h.rollout_cartesian(q, qd, prm, ox, ov, None, orad), iters=4),
+       rows * H, sb * (43 + 7 * M * H + 14) / H, "rollout_steps")
 # the two halves of a robot-sharded rollout step, all robots on this GPU
-sph = torch.empty((N, S, 9, B), dtype=h.dtype, device="cuda")
+SX = h.exchange_spheres
+sph = torch.empty((N, SX, 9, B), dtype=h.dtype, device="cuda")
 ssq = torch.zeros((rows,), dtype=h.dtype, device="cuda")
 qq, qqd = q.clone(), qd.clone()
-report("k_step_predict", timed(lambda: h.step_predict(B, 0, N, qq, qqd, sph)), rows, sb * (21 + 9 * S), "rows")
+report("k_step_predict", timed(lambda: h.step_predict(B, 0, N, qq, qqd, sph)), rows, sb * (21 + 9 * SX), "rows")
 qq, qqd = q.clone(), qd.clone()
 h.step_predict(B, 0, N, qq, qqd, sph)
 report("k_step_action", timed(lambda: h.step_action(B, 0, N, qq, qd.clone(), prm, sph, ssq)), rows,
-       sb * (14 + 29 + 9 * S * (N - 1) + 8), "rows")
+       sb * (14 + 29 + 9 * SX * (N - 1) + 8), "rows")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"dtype": dtype, "scenarios": B, "robots": N, "kernels": out},
           open(os.path.join(ROOT, "gpurun_out", f"prof_kernels_{dtype}.json"), "w"), indent=1)
