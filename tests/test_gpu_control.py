@@ -182,3 +182,22 @@ def test_episode_without_rollouts_is_plain_mrdf(oracle):
         act = ha.compute_action_coupled(qq, qdd, prm)
         ha.apply_action(qq, qdd, act, config.PANDA_VEL_LIMITS, stop_margin=1e-3)
     assert torch.equal(loop.q, qq) and torch.equal(loop.qdot, qdd)
+
+
+def test_episode_monitor_only_equals_never_triggering_deadlock_logic():
+    """dl = NULL (rollouts monitored, no deadlock logic) == deadlock logic whose trigger can never fire."""
+    N, B, STEPS = 3, 7, 14
+    cfg_roll = config.panda_config(n_robots=N, horizon=5)
+    cfg_roll.goal_estimate_mask = 0b110
+    cfg_act = config.panda_config(n_robots=N, horizon=1)
+    batch = scenarios.panda_batch(cfg_roll, B, seed=8, qd_spread=0.2)
+    hr, ha = FabricHandle(cfg_roll, 0), FabricHandle(cfg_act, 0)
+    q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    a = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=False, apply_estimate=True, use_graph=False)
+    b = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=True, apply_estimate=True, use_graph=True)
+    b.dl_cfg.avg_vel_constant = -1.0
+    a.run(STEPS)
+    b.run(STEPS)
+    assert torch.equal(a.q, b.q) and torch.equal(a.qdot, b.qdot) and torch.equal(a.avg, b.avg)
+    assert int(b.dl_state[abi.DL_TIME_IN_DEADLOCK].sum()) == 0
+    assert a.dl_state is None
