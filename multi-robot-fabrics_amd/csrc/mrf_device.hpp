@@ -906,10 +906,10 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
   MRF_MARK("finish");
 }
 
-// One fabric solve of a Panda row.  `obstacles(E, acc)` adds the spherical-obstacle leaves.  The own chain is
-// walked twice: once for the ego points the obstacle loop needs (positions, velocities), once afterwards for the
-// joint axes / origins / curvature terms of the pullback -- recomputing ~300 flops is cheaper than keeping
-// ~60 more values live across the loop (register pressure is what limits these kernels).
+// One fabric solve of a Panda row.  `obstacles(E, acc)` adds the spherical-obstacle leaves.  Two forms, chosen per
+// kernel (register pressure is what limits these kernels): SINGLE_WALK = false walks the own chain twice -- once
+// for the ego points the obstacle loop needs, once afterwards for the joint axes / origins / curvature terms of the
+// pullback -- because recomputing ~400 instructions is cheaper than spilling ~60 values around a heavy loop.
 struct NoPublish {
   template <typename K>
   __device__ __forceinline__ void operator()(const K&) const {}

@@ -1,11 +1,14 @@
 // mrf_kernels.hip -- gfx950 kernels and the C ABI of include/mrf.h.
 //
-// Kernels (all templated on the scalar type, one thread per (scenario, robot) row):
-//   k_action_panda / k_action_planar   batched compute_action                 (EXJ:441,444; pointmass :191-199)
-//   k_rollout_panda                    coupled joint-space Rollout Fabrics     (FPJ:190-249)
-//   k_rollout_cart_panda               Cartesian constant-velocity rollout     (FPC:421-458)
-//   k_fk_spheres_panda                 sphere x, v, jac_dot*qd                 (utils.py:16-54,87-119)
+// Kernels (all templated on the scalar type; one thread per (scenario, robot) row unless noted):
+//   k_action_panda / k_action_planar   batched compute_action, obstacles in HBM   (EXJ:441,444; pointmass :191-199)
+//   k_action_coupled                   compute_action of all robots, obstacle assembly on chip (EXJ:394-448)
+//   k_rollout_panda                    coupled joint-space Rollout Fabrics         (FPJ:190-249)
+//   k_coop_panda                       the two coupled kernels for small batches: one WAVE per scenario
+//   k_rollout_cart_panda               Cartesian constant-velocity rollout         (FPC:421-458)
+//   k_fk_spheres_panda                 sphere x, v, jac_dot*qd                     (utils.py:16-54,87-119)
 //   k_step_predict / k_step_action     the two halves of one robot-sharded rollout step
+// The control-step glue (hand FK, deadlock logic, integration, episodes) lives in mrf_control.hip.
 //
 // Layout: every array is component-major over rows (a[c*rows + row]) so that consecutive lanes touch
 // consecutive addresses on every load and store.
@@ -121,7 +124,9 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 // Link-origin sphere table (the reference's rollouts, PM:25-26): every lane already has its own robot's link
 // origins, velocities and Jdot*qdot from its own chain walk, so it stages them once in a per-wave LDS tile
 // [72][64] (8 links x (x, v, a)) and reads the other robots' entries from there -- no lane re-walks another
-// robot's chain.  4 resident waves x 36.9 KB (f64) fit the CU's 160 KB.
+// robot's chain.  4 resident waves x 36.9 KB (f64) fit the CU's 160 KB.  The origins of links 1/2 and 5/6
+// coincide (zero joint offsets): with equal radii such a pair occupies ONE slot of the tile and is folded once
+// with weight 2 (DevCfg::lo_merge01 / lo_merge45, set by the host).
 // slot of link-origin sphere sp (0..7) in the tile once coincident spheres are merged (DevCfg::lo_merge*)
 __device__ __forceinline__ int lo_slot(int sp, int m01, int m45) { return sp - (sp >= 1 ? m01 : 0) - (sp >= 5 ? m45 : 0); }
 // first sphere of a slot and the number of spheres merged into it
@@ -245,8 +250,9 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
 // ---------------------------------------------------------------------------- coupled joint-space rollout
 // One wave per block.  Lanes are (scenario, robot) pairs with the N robots of a scenario adjacent, so the
 // exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
-// stays inside the wave: each lane publishes cos q, sin q, qdot of its 7 joints to a 21 x 64 LDS tile and
-// re-walks the other robots' chains from that tile, streaming their spheres straight into its leaf sums.
+// stays inside the wave.  LO = true (link-origin sphere table): lanes exchange their link states through the
+// [72][64] tile above.  LO = false (any other table): each lane publishes cos q, sin q, qdot of its 7 joints to a
+// 21 x 64 LDS tile and re-walks the other robots' chains from it, streaming their spheres into its leaf sums.
 template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
 
 // ---------------------------------------------------------------------------- cooperative (latency) kernels
 // One wave per scenario for small batches, where the row-per-lane kernels above would leave the chip empty and a
-// single lane would walk through ~13 k instructions per rollout step.  Lane = (robot i, ego point g, sphere chunk c):
+// single lane would walk through ~7 k instructions per rollout step.  Lane = (robot i, ego point g, sphere chunk c):
 //   every lane walks its own robot's chain (redundantly, in parallel);
 //   one lane per robot stages that robot's sphere states (x, v, a) in LDS                       [LDS staging]
 //   each lane folds its ego point against its chunk of the other robots' spheres;
