@@ -458,3 +458,19 @@ def test_random_planner_configurations(oracle, seed):
         assert relerr(act.cpu().numpy(), want_act) < F64_RTOL, "compute_action action"
         act_c = h2.compute_action_coupled(q, qd, prm, use_accel=True)
         assert relerr(act_c.cpu().numpy(), want_act) < F64_RTOL, "coupled action"
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_rollout_large_time_step_takes_the_full_sincos_path(oracle, kernel):
+    """dt = 0.1 s makes |dq| exceed the 0.125 rad window of the incremental cos/sin update in some lanes, so the
+    wave falls back to full sincos evaluations (both paths must agree with the oracle)."""
+    cfg = config.panda_config(n_robots=3, horizon=4)
+    cfg.dt = 0.1
+    cfg.kernel_select = kernel
+    batch = scenarios.panda_batch(cfg, 21, seed=77, x_min=0.3, qd_spread=2.0)
+    assert np.abs(batch["qdot"]).max() * cfg.dt > 0.125
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    avg, tq, tqd = h.rollout(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), want_traj=True)
+    assert relerr(tq.cpu().numpy(), want_q) < F64_RTOL
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL
