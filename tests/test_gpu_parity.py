@@ -474,3 +474,21 @@ def test_rollout_large_time_step_takes_the_full_sincos_path(oracle, kernel):
     avg, tq, tqd = h.rollout(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), want_traj=True)
     assert relerr(tq.cpu().numpy(), want_q) < F64_RTOL
     assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL
+
+
+def test_joint_sincos_multi_revolution_angles(oracle):
+    """Joint angles far outside the joint limits (several revolutions, both signs, and beyond the fast path's 1e4 rad
+    window): the kernels' own range reduction must agree with the oracle's libm sin/cos."""
+    cfg = config.panda_config(n_robots=2, horizon=1)
+    rng = np.random.default_rng(2)
+    rows = 400
+    q = rng.uniform(-40.0, 40.0, (7, rows))
+    q[:, :20] = rng.uniform(-3e4, 3e4, (7, 20))               # library path
+    q[:, 20:27] = np.array([k * np.pi / 4 for k in range(-3, 4)])[None, :] * np.ones((7, 1))   # quadrant boundaries
+    qd = rng.uniform(-1, 1, (7, rows))
+    h = FabricHandle(cfg, 0)
+    x, v, a = h.fk_spheres(h.tensor(q), h.tensor(qd))
+    wx, wv, wa = oracle.fk_spheres(cfg, q, qd)
+    assert relerr(x.cpu().numpy(), wx) < 1e-11
+    assert relerr(v.cpu().numpy(), wv) < 1e-11
+    assert relerr(a.cpu().numpy(), wa) < 1e-11
