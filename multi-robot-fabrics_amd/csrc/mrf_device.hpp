@@ -744,7 +744,8 @@ struct PrmView {
   T g0[3];
   bool own_goal;  // x_goal_0 comes from g0 instead of memory
   __device__ __forceinline__ T operator[](int i) const {
-    if (i < 3 && own_goal) return g0[i];
+    // select chain instead of g0[i]: a runtime index would put g0 into scratch memory
+    if (i < 3 && own_goal) return i == 0 ? g0[0] : (i == 1 ? g0[1] : g0[2]);
     return base[i * rows + r];
   }
 };
