@@ -177,6 +177,12 @@ __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int l
   }
 }
 
+// The link-origin kernels keep the own chain's kinematics alive across the sphere loop (single walk) only with the
+// compile-time leaf policies; the runtime-family leaves need the registers, there the chain is re-walked instead
+// (the single-walk form spilled 544 B of scratch per lane in the generic instantiation).
+template <class LS>
+constexpr bool kSingleWalk = !LS::Collision::generic;
+
 constexpr int TILE_RADII = 72 * 64;  // per slot: sphere radius and multiplicity follow the [72][64] tile
 constexpr int TILE_MULT = TILE_RADII + 8;
 constexpr int TILE_SCALARS = TILE_MULT + 8;
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
     }
     T qdd[7], act[7];
     if constexpr (LO) {
-      panda_solve_row<LS, true>(
+      panda_solve_row<LS, kSingleWalk<LS>>(
           cfg, mount_own, R, P,
           [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
             obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
   PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
   T qdd[7], act[7];
   if constexpr (LO) {
-    panda_solve_row<LS, true>(
+    panda_solve_row<LS, kSingleWalk<LS>>(
         cfg, cfg.mount[li], R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);

@@ -17,6 +17,8 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 N, H = 3, 30
 cfg = config.panda_config(n_robots=N, horizon=H, scalar=abi.F64 if dtype == "f64" else abi.F32)
 cfg.goal_estimate_mask = 0b110
+if os.environ.get("MRF_GENERIC") == "1":   # leaf strings outside the reference's set -> runtime-family (generic) kernels
+    config.set_strings(cfg, collision_geometry="-0.5 / (x ** 3) * (xdot ** 2)")
 batch = scenarios.panda_batch(cfg, B, seed=1000)
 h = FabricHandle(cfg, 0)
 q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
