@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library (hipcc cross-compiles
+    # without a GPU) and the CPU oracle once, exactly as the driver's build check does
+    lib = os.path.join(ROOT, "multi-robot-fabrics_amd", "csrc", "libmrf_hip.so")
+    ora = os.path.join(ROOT, "oracle", "libmrf_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
