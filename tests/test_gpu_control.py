@@ -6,7 +6,6 @@
  * mrf_episode_run (plain launches and replayed HIP graph) against the oracle-side episode, f64 <= 1e-8 relative on q
    after 25 closed-loop steps (errors of the 1e-9 single-step tolerance accumulate through the recurrence).
 """
-import ctypes as C
 import os
 
 import numpy as np

@@ -11,7 +11,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from multi_robot_fabrics_amd import abi, config, scenarios
 from multi_robot_fabrics_amd.runtime import FabricHandle

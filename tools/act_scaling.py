@@ -1,7 +1,10 @@
-import os, sys
-sys.path.insert(0, '/root/repo')
-import numpy as np, torch
-from multi_robot_fabrics_amd import abi, config, scenarios
+#!/usr/bin/env python3
+"""compute_action (obstacles in HBM) time against the number of obstacle spheres at the bench batch."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multi_robot_fabrics_amd import config, scenarios
 from multi_robot_fabrics_amd.runtime import FabricHandle
 N=3
 cus = torch.cuda.get_device_properties(0).multi_processor_count

@@ -4,7 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd import config, scenarios
 from multi_robot_fabrics_amd.runtime import FabricHandle
 N, H = 3, 30
 base = config.panda_config(n_robots=N, horizon=H); base.goal_estimate_mask = 6

@@ -4,7 +4,7 @@ import sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd import config, scenarios
 from multi_robot_fabrics_amd.runtime import FabricHandle
 cfg = config.panda_config(n_robots=2, horizon=10)
 b = scenarios.panda_batch(cfg, 1, seed=0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rollout-kernel timing for the BASELINE.json configurations other than the bench workload (kernel only)."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -8,7 +8,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 from multi_robot_fabrics_amd import abi, config, scenarios
 from multi_robot_fabrics_amd.runtime import FabricHandle
