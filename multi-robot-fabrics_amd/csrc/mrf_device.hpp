@@ -791,7 +791,8 @@ __device__ __forceinline__ void panda_ego_points(const PandaKin<T>& K, const PRM
 }
 
 // Everything after the obstacle loop: plane + pullbacks + limits + attractors + solves + damping.
-template <class LS, typename T, class PRM>
+// PLANE_DONE: the caller has already added the plane leaves to acc (the cooperative kernels do it per lane).
+template <class LS, bool PLANE_DONE = false, typename T, class PRM>
 __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const PandaState<T>& R, const PRM& prm,
                                                  const PandaKin<T>& K, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc,
                                                  T (&qdd)[7], T (&act)[7]) {
@@ -800,7 +801,7 @@ __device__ __forceinline__ void panda_finish_row(const DevCfg<T>& cfg, const Pan
 #pragma unroll
   for (int j = 0; j < 7; ++j) S.M[tri<7>(j, j)] = cfg.base_mass;
   if (cfg.n_ego > 0) {
-    if (cfg.n_planes > 0) {
+    if (!PLANE_DONE && cfg.n_planes > 0) {
       T con[4] = {prm[MRF_P_CONSTRAINT_0], prm[MRF_P_CONSTRAINT_0 + 1], prm[MRF_P_CONSTRAINT_0 + 2], prm[MRF_P_CONSTRAINT_0 + 3]};
       accumulate_plane<typename LS::Plane>(cfg, E, con, acc);
     }

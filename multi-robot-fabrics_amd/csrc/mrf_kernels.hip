@@ -632,6 +632,11 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
                                                     a1, LO ? T(lo_count(sp, m01, m45)) : T(1));
       }
     }
+    // ---- the plane leaf of my point, once per point (chunk 0), instead of all 5 points redundantly in the finish
+    if (cfg.n_ego > 0 && cfg.n_planes > 0 && c == 0) {
+      T con[4] = {P[MRF_P_CONSTRAINT_0], P[MRF_P_CONSTRAINT_0 + 1], P[MRF_P_CONSTRAINT_0 + 2], P[MRF_P_CONSTRAINT_0 + 3]};
+      accumulate_plane<typename LS::Plane>(cfg, E1, con, a1);
+    }
     // ---- sum the chunk partials, then give every lane of the robot all 5 points
     for (int off = 1; off < C; off <<= 1) {
 #pragma unroll
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     EgoPts<T, NG> E;
     panda_ego_points(K, P, E);
     T qdd[7], act[7];
-    panda_finish_row<LS>(cfg, R, P, K, E, acc, qdd, act);
+    panda_finish_row<LS, true>(cfg, R, P, K, E, acc, qdd, act);
     if (COOP_ROLLOUT) {
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
