@@ -58,6 +58,7 @@ def main():
     min_limit = torch.full((B * N,), 1e9, dtype=h.dtype, device="cuda")
     reached_at = torch.full((B * N,), -1, dtype=torch.int64, device="cuda")
     avg_hist = []
+    bad_rollouts = 0
     loop = ControlLoop(h, roll, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=args.deadlock, apply_estimate=False,
                        stop_margin=1e-3)
     t = -1
@@ -67,7 +68,11 @@ def main():
         t += n
         q, qd = loop.q, loop.qdot
         if roll is not None:
-            avg_hist.append(float(loop.avg.mean()))
+            # a state parked on a hard joint stop sits 1e-3 rad from a limit barrier: the 30-step explicit-Euler
+            # prediction from there can step across the barrier and blow up (the reference's rollouts have no stops
+            # either); such rows are counted, not averaged
+            avg_hist.append(float(torch.nanmean(loop.avg)))
+            bad_rollouts = max(bad_rollouts, int((~torch.isfinite(loop.avg)).sum()))
         if True:  # statistics on the state after these steps
             x, _, _ = h.fk_spheres(q)                                  # [S,3,rows]
             xs = x.view(S, 3, B, N)
@@ -97,6 +102,7 @@ def main():
     }
     if avg_hist:
         out["rollout_avg_velocity_first_last"] = [avg_hist[0], avg_hist[-1]]
+        out["max_rows_with_nonfinite_rollout_prediction"] = bad_rollouts
     if loop.dl_state is not None:
         from multi_robot_fabrics_amd import abi as _abi
         tid = loop.dl_state[_abi.DL_TIME_IN_DEADLOCK]
