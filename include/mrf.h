@@ -222,7 +222,8 @@ int64_t mrf_deadlock_config_sizeof(void); /* sizeof(mrf_deadlock_config) as comp
 #define MRF_DL_TIME_IN_DEADLOCK 4
 #define MRF_DL_TIME_DEADLOCK_OUT 5 /* the driver's loop variable, initial value 1000 (EXJ:273) */
 #define MRF_DL_TIME_STEP 6         /* control-step counter w (EXJ:279), advanced by mrf_deadlock_step */
-#define MRF_DL_NSTATE 7
+#define MRF_DL_NONFINITE 7         /* control steps whose rollout average was not finite (the test DP:66 is then false) */
+#define MRF_DL_NSTATE 8
 int mrf_deadlock_init(mrf_handle* h, int64_t n_scenarios, int32_t* dl_state, void* dl_goal, void* stream);
 
 /* rows = n_scenarios * n_robots.  Copies params_nominal to params_work (they may alias), writes the hand position

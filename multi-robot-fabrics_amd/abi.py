@@ -83,7 +83,7 @@ EXPORTS = [
 ]
 
 # rows of the int32 deadlock state (include/mrf.h MRF_DL_*)
-DL_LEADER, DL_FOLLOWER, DL_DEAD0, DL_DEAD1, DL_TIME_IN_DEADLOCK, DL_TIME_DEADLOCK_OUT, DL_TIME_STEP, DL_NSTATE = range(8)
+DL_LEADER, DL_FOLLOWER, DL_DEAD0, DL_DEAD1, DL_TIME_IN_DEADLOCK, DL_TIME_DEADLOCK_OUT, DL_TIME_STEP, DL_NONFINITE, DL_NSTATE = range(9)
 
 
 class DeadlockConfig(C.Structure):

@@ -69,6 +69,9 @@ __global__ __launch_bounds__(64) void k_deadlock(const DevCfg<T>* __restrict__ c
   T avg_sum = T(0);  // vel_avg_tot = sum(vel_avg) / nr_robots  (EXJ:375)
   for (int i = 0; i < N; ++i) avg_sum += avg[r0 + i];
   avg_sum = avg_sum / T(N);
+  // A non-finite rollout signal (a state the rollout could not predict, e.g. parked on a hard joint stop) makes the
+  // reference's test `avg < constant` false, i.e. "no deadlock" -- kept, but counted so that the caller can see it.
+  if (!(m_abs(avg_sum) <= T(1.7e308))) st[MRF_DL_NONFINITE * n_scen + b] += 1;
 
   T X[MRF_MAX_ROBOTS][3], dist_goal[MRF_MAX_ROBOTS];
   int state[MRF_MAX_ROBOTS];
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(256) void k_deadlock_init(int64_t n_scen, int32_t* 
   st[MRF_DL_TIME_IN_DEADLOCK * n_scen + b] = 0;
   st[MRF_DL_TIME_DEADLOCK_OUT * n_scen + b] = 1000;  // EXJ:273
   st[MRF_DL_TIME_STEP * n_scen + b] = 0;
+  st[MRF_DL_NONFINITE * n_scen + b] = 0;
   for (int c = 0; c < 3; ++c) dl_goal[c * n_scen + b] = T(0);
 }
 
@@ -350,6 +354,11 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
                             params_work, sm_state, dl_state, dl_goal, x_ee_work, avg_work, action_out, (void*)st,
                             (void*)(intptr_t)(dl != nullptr)};
   std::string key((const char*)key_ptrs, sizeof(key_ptrs));
+  // what the captured launches bake in besides the arguments: the handles' constants (a destroyed handle's address
+  // can be handed to a new one: the creation serial tells them apart), and the kernel variant chosen from the config
+  const uint64_t ident[] = {ha->serial, hr ? hr->serial : 0, (uint64_t)(uintptr_t)ha->dcfg,
+                            (uint64_t)(uintptr_t)(hr ? hr->dcfg : nullptr)};
+  key.append((const char*)ident, sizeof(ident));
   key.append((const char*)&dlc, sizeof(dlc));
   key.append((const char*)vel_limit, sizeof(double) * MRF_DOF_MAX);
   key.append((const char*)&stop_margin, sizeof(stop_margin));

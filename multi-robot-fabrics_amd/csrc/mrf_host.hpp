@@ -10,6 +10,7 @@
 struct mrf_handle {
   mrf_config cfg;
   int device;
+  uint64_t serial;        // process-wide creation counter: distinguishes a new handle that reuses a freed address
   int64_t coop_max_scen;  // batches up to this size use the cooperative kernels (auto mode)
   void* dcfg;             // DevCfg<double> or DevCfg<float> on the device
   std::string err;
@@ -21,6 +22,22 @@ struct mrf_handle {
 };
 
 namespace mrf_host {
+
+// Every entry point runs on the handle's device, whatever the calling thread's current device is, and leaves the
+// caller's current device as it found it (a process that drives several GPUs, or torch after set_device(local_rank)).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (device < 0 || hipGetDevice(&prev) != hipSuccess) return;
+    if (prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 inline int fail(mrf_handle* h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -45,6 +62,9 @@ int dispatch_scalar(mrf_handle* h, F f) {
 
 }  // namespace mrf_host
 
-#define MRF_CHECK_READY(h)                              \
-  if (!(h)) return MRF_E_ARG;                           \
-  if (!(h)->dcfg) return mrf_host::fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)");
+#define MRF_GUARD_CAT2(a, b) a##b
+#define MRF_GUARD_CAT(a, b) MRF_GUARD_CAT2(a, b)
+#define MRF_CHECK_READY(h)                                                                                    \
+  if (!(h)) return MRF_E_ARG;                                                                                 \
+  if (!(h)->dcfg) return mrf_host::fail((h), MRF_E_DEVICE, "handle has no device state (mrf_create failed)"); \
+  mrf_host::DeviceGuard MRF_GUARD_CAT(mrf_device_guard_, __LINE__)((h)->device);

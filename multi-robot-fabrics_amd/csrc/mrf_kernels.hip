@@ -14,6 +14,7 @@
 // consecutive addresses on every load and store.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -1128,8 +1129,10 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
   *out = nullptr;
   mrf_handle* h = new (std::nothrow) mrf_handle();
   if (!h) return MRF_E_ARG;
+  static std::atomic<uint64_t> next_serial{1};
   h->cfg = *cfg;
   h->device = device_id;
+  h->serial = next_serial.fetch_add(1);
   h->dcfg = nullptr;
   *out = h;  // returned even on failure so that mrf_last_error() can be read; caller destroys it
   std::string v = validate(*cfg);
@@ -1138,7 +1141,9 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(h, MRF_E_DEVICE, "no HIP device available (there is no CPU path)");
   if (device_id < 0 || device_id >= ndev) return fail(h, MRF_E_DEVICE, "device_id out of range");
-  if (hipSetDevice(device_id) != hipSuccess) return fail(h, MRF_E_DEVICE, "hipSetDevice failed");
+  mrf_host::DeviceGuard guard(device_id);  // upload on the handle's device, then restore the caller's current device
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device_id) return fail(h, MRF_E_DEVICE, "hipSetDevice failed");
   hipError_t e;
   if (cfg->scalar == MRF_F64) {
     mrf::DevCfg<double> d;
@@ -1163,6 +1168,7 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
 
 void mrf_destroy(mrf_handle* h) {
   if (!h) return;
+  mrf_host::DeviceGuard guard(h->dcfg ? h->device : -1);
   if (h->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)h->graph_exec);
   if (h->own_stream) (void)hipStreamDestroy((hipStream_t)h->own_stream);
   if (h->dcfg) (void)hipFree(h->dcfg);

@@ -122,12 +122,14 @@ class _SphereEvaluator:
         cfg = _config.panda_config(n_robots=1, horizon=1, mounts=[mount])
         _config.set_spheres(cfg, links, offsets)
         self.S = len(links)
-        self.h = FabricHandle(cfg, 0)
+        self.h = FabricHandle(cfg, getattr(self, "device", None))
 
     @classmethod
     def get(cls, mount, links, offsets=None):
         offsets = [(0.0, 0.0, 0.0)] * len(links) if offsets is None else [tuple(float(v) for v in o) for o in offsets]
-        key = (np.asarray(mount, dtype=float).tobytes(), tuple(links), tuple(offsets))
+        import torch
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else -1   # handles are per device
+        key = (dev, np.asarray(mount, dtype=float).tobytes(), tuple(links), tuple(offsets))
         if key not in cls._cache:
             cls._cache[key] = cls(mount, list(links), offsets)
         return cls._cache[key]

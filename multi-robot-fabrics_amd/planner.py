@@ -175,7 +175,7 @@ class ParameterizedFabricPlanner:
         self._mode = mode
         self.config = cfg
         from .runtime import FabricHandle
-        self._handle = FabricHandle(cfg, 0)      # raises without the HIP library or a GPU: there is no CPU path
+        self._handle = FabricHandle(cfg, getattr(self, "device", None))      # raises without the HIP library or a GPU: there is no CPU path
         self._funs = _Funs(self)
 
     # ------------------------------------------------------------------ evaluation

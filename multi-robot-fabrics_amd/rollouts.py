@@ -97,7 +97,7 @@ class ForwardFabricsPlanner:
             setattr(cfg, key, val)
         from .runtime import FabricHandle
         self.config = cfg
-        self._handle = FabricHandle(cfg, 0)
+        self._handle = FabricHandle(cfg, getattr(self, "device", None))
         return {}
 
     # -- argument marshalling (FPJ:303-329) ------------------------------------------------------------------------
@@ -236,7 +236,7 @@ class FabricsRollouts:
         from .runtime import FabricHandle
         self.config = cfg
         self._planner = planner
-        self._handle = FabricHandle(cfg, 0)
+        self._handle = FabricHandle(cfg, getattr(self, "device", None))
         return {}
 
     def define_arguments_numerical(self, q_robot, q_dot_robot, weight_goals, x_goals, x_obsts, x_obsts_dyn, v_obsts_dyn,

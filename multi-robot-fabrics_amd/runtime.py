@@ -22,12 +22,20 @@ def _dtype(cfg):
 class FabricHandle:
     """Owns an `mrf_handle` (immutable constants on the device).  Not thread-safe, like the C handle."""
 
-    def __init__(self, cfg, device=0):
+    def __init__(self, cfg, device=None):
+        """device: index / torch.device; None = torch's current device (so that a rank that called
+        torch.cuda.set_device(local_rank) gets its own GPU).  The C handle pins its device: calls run there whatever
+        the current device is, and leave the current device untouched."""
         self.lib = abi.load_library()
         if not torch.cuda.is_available():
             raise MrfError("no HIP device visible to torch; the fabric solve has no CPU fallback")
         self.cfg = cfg.copy()
-        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        if device is None:
+            device = torch.cuda.current_device()
+        if not isinstance(device, int):
+            d = torch.device(device)
+            device = torch.cuda.current_device() if d.index is None else d.index
+        self.device = torch.device("cuda", device)
         self.dtype = _dtype(cfg)
         self.dof = 7 if cfg.model == abi.MODEL_PANDA7 else 3
         self._h = C.c_void_p()
@@ -83,9 +91,11 @@ class FabricHandle:
             raise MrfError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return C.c_void_p(t.data_ptr())
 
-    @staticmethod
-    def _stream(stream):
-        s = torch.cuda.current_stream() if stream is None else stream
+    def _stream(self, stream):
+        """Stream to launch on: the caller's, or torch's current stream OF THE HANDLE'S DEVICE."""
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        if getattr(s, "device", self.device) != self.device:
+            raise MrfError(f"stream belongs to {s.device}, the handle to {self.device}")
         return C.c_void_p(s.cuda_stream)
 
     # ------------------------------------------------------------------ entry points
@@ -260,8 +270,21 @@ class ControlLoop:
     def __init__(self, h_action, h_rollout, q, qdot, params, vel_limit, deadlock=True, apply_estimate=True,
                  stop_margin=1e-3, sm_state=None, use_graph=True):
         self.ha, self.hr = h_action, h_rollout
-        self.q, self.qdot, self.params = q.clone(), qdot.clone(), params
+        if h_rollout is not None and (h_rollout.dtype != h_action.dtype or h_rollout.device != h_action.device or
+                                      h_rollout.cfg.n_robots != h_action.cfg.n_robots):
+            raise MrfError("rollout and action handles must agree in scalar type, device and n_robots")
+        if q.dim() != 2 or q.shape[0] != h_action.dof or q.shape[1] % h_action.cfg.n_robots:
+            raise MrfError(f"q: expected [{h_action.dof}, n_scenarios * {h_action.cfg.n_robots}], got {tuple(q.shape)}")
         rows = q.shape[1]
+        # own, contiguous copies of the state (advanced in place); `params` is NOT copied: the caller may rewrite goals
+        # between run() calls (the replayed graph reads the same buffer), so it must already be a valid device array
+        self.q, self.qdot = q.clone().contiguous(), qdot.clone().contiguous()
+        self.params = params
+        h_action._arg(self.q, (h_action.dof, rows), "q")
+        h_action._arg(self.qdot, (h_action.dof, rows), "qdot")
+        h_action._arg(self.params, (abi.NPARAM, rows), "params")
+        if len(vel_limit) != h_action.dof:
+            raise MrfError(f"vel_limit: expected {h_action.dof} values")
         self.n_scen = rows // h_action.cfg.n_robots
         self.params_work = torch.empty_like(params)
         self.x_ee = torch.empty((3, rows), dtype=h_action.dtype, device=h_action.device)
@@ -271,6 +294,9 @@ class ControlLoop:
         self.stop_margin = float(stop_margin)
         self.apply_estimate = bool(apply_estimate)
         self.sm_state = sm_state
+        FabricHandle._i32(sm_state, (rows,), "sm_state")
+        if sm_state is not None and sm_state.device != h_action.device:
+            raise MrfError(f"sm_state lives on {sm_state.device}, the handles on {h_action.device}")
         self.use_graph = bool(use_graph)
         self.dl_cfg = h_action.deadlock_config() if (deadlock and h_rollout is not None) else None
         self.dl_state, self.dl_goal = (h_rollout.deadlock_state(self.n_scen) if self.dl_cfg is not None else (None, None))
@@ -282,6 +308,6 @@ class ControlLoop:
                                     C.byref(self.dl_cfg) if self.dl_cfg is not None else None, int(self.apply_estimate),
                                     self.vel_limit, self.stop_margin, p(self.q), p(self.qdot), p(self.params),
                                     p(self.params_work), p(self.sm_state), p(self.dl_state), p(self.dl_goal), p(self.x_ee),
-                                    p(self.avg), p(self.action), int(self.use_graph), FabricHandle._stream(stream))
+                                    p(self.avg), p(self.action), int(self.use_graph), ha._stream(stream))
         ha._check(rc)
         return self.action

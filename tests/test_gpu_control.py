@@ -200,3 +200,63 @@ def test_episode_monitor_only_equals_never_triggering_deadlock_logic():
     assert torch.equal(a.q, b.q) and torch.equal(a.qdot, b.qdot) and torch.equal(a.avg, b.avg)
     assert int(b.dl_state[abi.DL_TIME_IN_DEADLOCK].sum()) == 0
     assert a.dl_state is None
+
+
+def test_control_loop_rejects_malformed_inputs():
+    """ControlLoop validates once what mrf_episode_run will dereference: dtype, device, shape, contiguity."""
+    from multi_robot_fabrics_amd.runtime import MrfError
+    N, B = 3, 4
+    cfg = config.panda_config(n_robots=N, horizon=1)
+    ha = FabricHandle(cfg, 0)
+    batch = scenarios.panda_batch(cfg, B, seed=2)
+    q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    with pytest.raises(MrfError):
+        ControlLoop(ha, None, q.float(), qd, prm, config.PANDA_VEL_LIMITS)               # f32 state on an f64 handle
+    with pytest.raises(MrfError):
+        ControlLoop(ha, None, q, qd, prm.cpu(), config.PANDA_VEL_LIMITS)                 # host params
+    with pytest.raises(MrfError):
+        ControlLoop(ha, None, q[:, :-1], qd[:, :-1], prm[:, :-1], config.PANDA_VEL_LIMITS)  # rows not a multiple of N
+    with pytest.raises(MrfError):
+        ControlLoop(ha, None, q, qd, prm, config.PANDA_VEL_LIMITS, sm_state=torch.zeros(B * N, dtype=torch.int64, device="cuda"))
+    # a dense transposed view is made contiguous by the loop's own copy
+    loop = ControlLoop(ha, None, q.t().contiguous().t(), qd, prm, config.PANDA_VEL_LIMITS, use_graph=False)
+    assert loop.q.is_contiguous()
+    loop.run(1)
+
+
+def test_cached_graph_is_not_replayed_for_a_new_rollout_handle():
+    """The graph cached in the action handle is keyed by the handles' creation serials and constant buffers: a rollout
+    handle destroyed and recreated with another horizon must not replay the launches captured for the old one."""
+    N, B = 3, 6
+    cfg_act = config.panda_config(n_robots=N, horizon=1)
+    ha = FabricHandle(cfg_act, 0)
+    results = {}
+    for H in (3, 9, 3):
+        cfg_roll = config.panda_config(n_robots=N, horizon=H)
+        batch = scenarios.panda_batch(cfg_roll, B, seed=5, qd_spread=0.2)
+        hr = FabricHandle(cfg_roll, 0)
+        q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+        g = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=False, use_graph=True)
+        p = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=False, use_graph=False)
+        g.run(3)
+        p.run(3)
+        torch.cuda.synchronize()
+        assert torch.equal(g.avg, p.avg) and torch.equal(g.q, p.q), H
+        results.setdefault(H, g.avg.clone())
+        hr.close()
+    assert not torch.equal(results[3], results[9])
+
+
+def test_nonfinite_rollout_signal_is_counted():
+    N, B = 2, 3
+    cfg = config.panda_config(n_robots=N, horizon=1)
+    h = FabricHandle(cfg, 0)
+    dl = h.deadlock_config()
+    st, goal = h.deadlock_state(B)
+    prm = torch.zeros((abi.NPARAM, B * N), dtype=torch.float64, device="cuda")
+    x_ee = torch.rand((3, B * N), dtype=torch.float64, device="cuda")
+    avg = torch.full((B * N,), 0.01, dtype=torch.float64, device="cuda")
+    avg[2] = float("nan")        # scenario 1
+    for _ in range(4):
+        h.deadlock_step(dl, x_ee, avg, prm, st, goal)
+    assert st[abi.DL_NONFINITE].tolist() == [0, 4, 0]
