@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--shard", choices=["scenarios", "robots"], default="scenarios")
+    ap.add_argument("--transport", choices=["rccl", "peer", "torch"], default="rccl",
+                    help="--shard robots: exchange inside the library over RCCL (default) or peer-mapped buffers, or the Python loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MRF_ABI_VERSION 1
+#define MRF_ABI_VERSION 2
 #define MRF_MAX_ROBOTS 16
 #define MRF_MAX_SPHERES 32 /* exchanged spheres per robot */
 #define MRF_DOF_MAX 7
@@ -180,10 +180,55 @@ int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot,
  * receiver counts it twice) -- 6 instead of 8 for the reference's rollout table.
  */
 int32_t mrf_exchange_spheres(const mrf_handle* h);
+/* Once per rollout, before the first step: params_out := params with x_goal_0 replaced by x_ee + goal_estimate_T * v_ee
+ * for the owned robots in cfg.goal_estimate_mask (RF-CV, EXC:355-357) -- what mrf_rollout does in its prologue. */
+int mrf_step_prepare(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
+                     const void* qdot, const void* params, void* params_out, void* stream);
 int mrf_step_predict(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, void* q_io,
                      const void* qdot, void* sph_own, void* stream);
 int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
                     void* qdot_io, const void* params, const void* sph_all, void* sumsq_io, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Robot-sharded rollout INSIDE the library (SURVEY 8b "mrf_comm_init / mrf_rollout_sharded", 8e).
+ * A group of `world` processes, one per GPU, shares the robots of every scenario: rank r owns the contiguous robot
+ * block that mrf_comm_partition() reports (block sizes differ by at most one).  mrf_rollout_sharded runs the whole
+ * H-step recurrence of forward_planner_Jointspace.py:190-249 for the owned robots; the exchange step of that graph
+ * (FPJ:211-225: at step k every robot reads every other robot's predicted spheres x, v, a) is done by the library:
+ *
+ *   MRF_TRANSPORT_RCCL   per step: mrf_step_predict -> ncclAllGather (RCCL, over xGMI between GPUs) of the ranks' sphere
+ *                        blocks -> mrf_step_action, all enqueued on the caller's stream from C++ (no host round trip).
+ *                        librccl is dlopen'ed on first use; the library has no link-time dependency on it.
+ *   MRF_TRANSPORT_PEER   device-initiated exchange: every rank maps every other rank's exchange buffer
+ *                        (hipIpcGetMemHandle / hipIpcOpenMemHandle; the caller carries the 64-byte handles between the
+ *                        processes by whatever means it has); ONE persistent kernel per rollout walks the H steps and,
+ *                        per step, stores its robots' spheres straight into all peers' buffers, raises a per-workgroup
+ *                        flag there and polls the peers' flags for the same scenarios (bounded spin: a peer that never
+ *                        arrives ends the kernel and is reported by mrf_comm_status, it cannot hang the GPU).
+ *
+ * Every rank of the group must make the same sequence of mrf_rollout_sharded calls with the same n_scen.
+ *   q_io, qdot_io [dof][n_scen*count]  the OWNED rows, row = scenario*count + (robot - first); advanced in place
+ *   params        [MRF_NPARAM][n_scen*count]      avg_vel_out [n_scen*count]
+ */
+typedef enum { MRF_TRANSPORT_NONE = 0, MRF_TRANSPORT_RCCL = 1, MRF_TRANSPORT_PEER = 2 } mrf_transport;
+#define MRF_COMM_ID_BYTES 128   /* sizeof(ncclUniqueId) */
+#define MRF_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
+/* rank 0 of the group: a fresh communicator id (ncclGetUniqueId) to hand to every rank's mrf_comm_init */
+int mrf_comm_unique_id(void* id_out);
+/* RCCL transport.  world == 1 with unique_id == NULL creates a group of one without touching RCCL. */
+int mrf_comm_init(mrf_handle* h, int32_t rank, int32_t world, const void* unique_id);
+/* PEER transport, two phases around the caller's exchange of the handles: open allocates this rank's exchange buffer
+ * for up to max_scenarios scenarios and writes its IPC handle (MRF_IPC_HANDLE_BYTES); connect maps the peers' buffers
+ * from ipc_handles_all [world][MRF_IPC_HANDLE_BYTES] (rank order; the own entry is not opened). */
+int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_scenarios, void* ipc_handle_out);
+int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all);
+int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot_count);
+int32_t mrf_comm_transport(const mrf_handle* h);
+int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io, const void* params, void* avg_vel_out,
+                        void* stream);
+/* Waits for the stream of the last mrf_rollout_sharded and reports a timed-out exchange (MRF_E_LAUNCH) or MRF_OK. */
+int mrf_comm_status(mrf_handle* h);
+void mrf_comm_destroy(mrf_handle* h); /* also done by mrf_destroy */
 
 /* ------------------------------------------------------------------------------------------------------------
  * Device-resident control step: everything between two simulator steps of

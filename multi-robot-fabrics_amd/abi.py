@@ -6,7 +6,7 @@ The product path has no CPU fallback: if csrc/libmrf_hip.so is missing or cannot
 import ctypes as C
 import os
 
-MRF_ABI_VERSION = 1
+MRF_ABI_VERSION = 2
 MRF_MAX_ROBOTS = 16
 MRF_MAX_SPHERES = 32
 MRF_DOF_MAX = 7
@@ -77,10 +77,15 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
 EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
     "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
-    "mrf_fk_spheres", "mrf_exchange_spheres", "mrf_step_predict", "mrf_step_action",
+    "mrf_fk_spheres", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
+    "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
+    "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_destroy",
 ]
+
+TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2
+COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 
 # rows of the int32 deadlock state (include/mrf.h MRF_DL_*)
 DL_LEADER, DL_FOLLOWER, DL_DEAD0, DL_DEAD1, DL_TIME_IN_DEADLOCK, DL_TIME_DEADLOCK_OUT, DL_TIME_STEP, DL_NONFINITE, DL_NSTATE = range(9)
@@ -142,6 +147,8 @@ def load_library(path=None):
     lib.mrf_fk_spheres.restype = C.c_int
     lib.mrf_exchange_spheres.argtypes = [vp]
     lib.mrf_exchange_spheres.restype = i32
+    lib.mrf_step_prepare.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.mrf_step_prepare.restype = C.c_int
     lib.mrf_step_predict.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
     lib.mrf_step_predict.restype = C.c_int
     lib.mrf_step_action.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -162,6 +169,24 @@ def load_library(path=None):
     lib.mrf_episode_run.argtypes = [vp, vp, i64, i32, dlp, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, vp, vp,
                                     vp, vp, vp, vp, vp, i32, vp]
     lib.mrf_episode_run.restype = C.c_int
+    lib.mrf_comm_unique_id.argtypes = [vp]
+    lib.mrf_comm_unique_id.restype = C.c_int
+    lib.mrf_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.mrf_comm_init.restype = C.c_int
+    lib.mrf_comm_peer_open.argtypes = [vp, i32, i32, i64, vp]
+    lib.mrf_comm_peer_open.restype = C.c_int
+    lib.mrf_comm_peer_connect.argtypes = [vp, vp]
+    lib.mrf_comm_peer_connect.restype = C.c_int
+    lib.mrf_comm_partition.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.mrf_comm_partition.restype = C.c_int
+    lib.mrf_comm_transport.argtypes = [vp]
+    lib.mrf_comm_transport.restype = i32
+    lib.mrf_rollout_sharded.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.mrf_rollout_sharded.restype = C.c_int
+    lib.mrf_comm_status.argtypes = [vp]
+    lib.mrf_comm_status.restype = C.c_int
+    lib.mrf_comm_destroy.argtypes = [vp]
+    lib.mrf_comm_destroy.restype = None
     if lib.mrf_abi_version() != MRF_ABI_VERSION:
         raise MrfLibraryError(f"ABI mismatch: library {lib.mrf_abi_version()} != python {MRF_ABI_VERSION}")
     if lib.mrf_config_sizeof() != C.sizeof(Config):

@@ -962,6 +962,25 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
   panda_finish_row<LS>(cfg, R, prm, K, E, acc, qdd, act);
 }
 
+// ------------------------------------------------------------------------------------ link-origin sphere table
+// slot of link-origin sphere sp (0..7) in the tile once coincident spheres are merged (DevCfg::lo_merge*)
+__host__ __device__ __forceinline__ int lo_slot(int sp, int m01, int m45) { return sp - (sp >= 1 ? m01 : 0) - (sp >= 5 ? m45 : 0); }
+// first sphere of a slot and the number of spheres merged into it
+__host__ __device__ __forceinline__ int lo_sphere(int slot, int m01, int m45) {
+  const int sp = slot + (slot >= 1 ? m01 : 0);
+  return sp + (sp >= 5 ? m45 : 0);
+}
+__host__ __device__ __forceinline__ int lo_count(int slot, int m01, int m45) {
+  return ((slot == 0 && m01) || (slot == 4 - m01 && m45)) ? 2 : 1;
+}
+
+// The link-origin kernels keep the own chain's kinematics alive across the sphere loop (single walk) only with the
+// compile-time leaf policies; the runtime-family leaves need the registers, there the chain is re-walked instead
+// (the single-walk form spilled 544 B of scratch per lane in the generic instantiation).
+template <class LS>
+constexpr bool kSingleWalk = !LS::Collision::generic;
+
+
 // ------------------------------------------------------------------------------------ planar point robot
 // pointRobot1.urdf:91-113: prismatic x (origin z 0.05), prismatic y, revolute theta; collision link base_link.
 template <typename T>

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/mrf.h"
+#include "mrf_device.hpp"
 
 struct mrf_handle {
   mrf_config cfg;
@@ -19,6 +20,7 @@ struct mrf_handle {
   void* graph_exec = nullptr;
   std::string graph_key;
   void* own_stream = nullptr;
+  void* comm = nullptr;   // robot-sharded rollout state (mrf_comm.hip): communicator / mapped peer buffers / work buffers
 };
 
 namespace mrf_host {
@@ -59,6 +61,49 @@ template <typename F>
 int dispatch_scalar(mrf_handle* h, F f) {
   return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
 }
+
+
+// the reference's Panda leaf strings (EXJ:87-89 + the library's limit / plane-Finsler defaults) get compile-time
+// leaf policies; any other configuration runs the generic (runtime-family) instantiation
+using LeafSetPanda = mrf::LeafSet<mrf::LeafPow<4, 4, MRF_GATE_NONE, MRF_GATE_NONE>,
+                                  mrf::SLeaf<MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE, 1, MRF_GATE_NEG>,
+                                  mrf::SLeaf<MRF_FAMILY_POW, 1, MRF_GATE_NONE, 1, MRF_GATE_NEG>>;
+using LeafSetGeneric = mrf::LeafSet<mrf::LeafGeneric, mrf::SLeafGeneric, mrf::SLeafGeneric>;
+inline bool leaf_is(const mrf_leaf_fn& f, int family, int p, int gate) {
+  return f.family == family && f.gate == gate && (family == MRF_FAMILY_LOGISTIC || f.p == p);
+}
+inline bool is_panda_leafset(const mrf_config& c) {
+  return leaf_is(c.collision_geometry, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
+         leaf_is(c.collision_finsler, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
+         leaf_is(c.plane_geometry, MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE) &&
+         leaf_is(c.plane_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG) &&
+         leaf_is(c.limit_geometry, MRF_FAMILY_POW, 1, MRF_GATE_NONE) &&
+         leaf_is(c.limit_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG);
+}
+
+// the reference's rollout sphere table: the origins of panda_link1..8 (PM:25-26)
+inline bool is_link_origin_table(const mrf_config& c) {
+  if (c.n_spheres != 8) return false;
+  for (int s = 0; s < 8; ++s)
+    if (c.sphere_link[s] != s + 1 || c.sphere_offset[s][0] != 0.0 || c.sphere_offset[s][1] != 0.0 ||
+        c.sphere_offset[s][2] != 0.0)
+      return false;
+  return true;
+}
+
+template <typename F>
+int dispatch(mrf_handle* h, F f) {  // f(scalar tag, leaf-set tag)
+  const bool fast = is_panda_leafset(h->cfg);
+  if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafSetPanda{}) : f(double{}, LeafSetGeneric{});
+  return fast ? f(float{}, LeafSetPanda{}) : f(float{}, LeafSetGeneric{});
+}
+
+// mrf_step_action with an explicit robot -> block-position map of sph_all (padded all-gather layouts); NULL = identity
+int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
+                      void* qdot_io, const void* params, const void* sph_all, const int32_t* robot_slot, void* sumsq_io,
+                      void* stream);
+// frees h->comm (mrf_comm.hip); called by mrf_destroy
+void comm_release(mrf_handle* h);
 
 }  // namespace mrf_host
 

@@ -128,17 +128,6 @@ __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restri
 // robot's chain.  4 resident waves x 36.9 KB (f64) fit the CU's 160 KB.  The origins of links 1/2 and 5/6
 // coincide (zero joint offsets): with equal radii such a pair occupies ONE slot of the tile and is folded once
 // with weight 2 (DevCfg::lo_merge01 / lo_merge45, set by the host).
-// slot of link-origin sphere sp (0..7) in the tile once coincident spheres are merged (DevCfg::lo_merge*)
-__device__ __forceinline__ int lo_slot(int sp, int m01, int m45) { return sp - (sp >= 1 ? m01 : 0) - (sp >= 5 ? m45 : 0); }
-// first sphere of a slot and the number of spheres merged into it
-__device__ __forceinline__ int lo_sphere(int slot, int m01, int m45) {
-  const int sp = slot + (slot >= 1 ? m01 : 0);
-  return sp + (sp >= 5 ? m45 : 0);
-}
-__device__ __forceinline__ int lo_count(int slot, int m01, int m45) {
-  return ((slot == 0 && m01) || (slot == 4 - m01 && m45)) ? 2 : 1;
-}
-
 template <typename T>
 __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int lane, const PandaKin<T>& K, bool dyn,
                                                       bool acc_on, T jsign, int m01, int m45) {
@@ -177,12 +166,6 @@ __device__ __forceinline__ void publish_link_spheres(T* __restrict__ tile, int l
       for (int k3 = 0; k3 < 3; ++k3) tile[(sp * 9 + 6 + k3) * 64 + lane] = T(0);
   }
 }
-
-// The link-origin kernels keep the own chain's kinematics alive across the sphere loop (single walk) only with the
-// compile-time leaf policies; the runtime-family leaves need the registers, there the chain is re-walked instead
-// (the single-walk form spilled 544 B of scratch per lane in the generic instantiation).
-template <class LS>
-constexpr bool kSingleWalk = !LS::Collision::generic;
 
 constexpr int TILE_RADII = 72 * 64;  // per slot: sphere radius and multiplicity follow the [72][64] tile
 constexpr int TILE_MULT = TILE_RADII + 8;
@@ -825,12 +808,17 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
       });
 }
 
-// action: fabric solve of the owned robots against every other robot's published spheres.
+// action: fabric solve of the owned robots against every other robot's published spheres.  slots.s[j] is the
+// position of robot j's block in sph_all (identity for the [n_robots][SX][9][B] layout of the C ABI; the padded
+// [rank][cnt_max] layout of an all-gather with uneven robot blocks otherwise).
+struct RobotSlots {
+  int s[MRF_MAX_ROBOTS];
+};
 template <typename T, class LS>
 __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
                                                       int robot_count, const T* __restrict__ q, T* __restrict__ qd_io,
                                                       const T* __restrict__ prm, const T* __restrict__ sph_all,
-                                                      T* __restrict__ sumsq_io) {
+                                                      RobotSlots slots, T* __restrict__ sumsq_io) {
   const DevCfg<T>& cfg = *cfgp;
   const int64_t rows = n_scen * robot_count;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -857,7 +845,7 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
             // exchanged slots: coincident link origins (DevCfg::lo_merge*) arrive once and count twice
             const int s = lo_sphere(slot, m01, m45);
             const T mult = T(lo_count(slot, m01, m45));
-            const int64_t base = ((int64_t)(jr * SX + slot) * 9) * n_scen + scen;
+            const int64_t base = ((int64_t)(slots.s[jr] * SX + slot) * 9) * n_scen + scen;
             T x[3], v[3], a[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -886,7 +874,12 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
 namespace {
 
 using mrf_host::check_hip;
+using mrf_host::dispatch;
 using mrf_host::dispatch_scalar;
+using mrf_host::is_link_origin_table;
+using mrf_host::is_panda_leafset;
+using mrf_host::LeafSetGeneric;
+using mrf_host::LeafSetPanda;
 using mrf_host::fail;
 using mrf_host::launch;
 
@@ -900,8 +893,6 @@ void to_dev_leaf(const mrf_leaf_fn& s, mrf::LeafFn<T>& d) {
   d.c = (T)s.c;
   d.s = (T)s.s;
 }
-
-bool is_link_origin_table(const mrf_config& c);
 
 template <typename T>
 void to_dev_cfg(const mrf_config& c, mrf::DevCfg<T>& d) {
@@ -993,34 +984,6 @@ std::string validate(const mrf_config& c) {
   return "";
 }
 
-// the reference's Panda leaf strings (EXJ:87-89 + the library's limit / plane-Finsler defaults) get compile-time
-// leaf policies; any other configuration runs the generic (runtime-family) instantiation
-using LeafSetPanda = mrf::LeafSet<mrf::LeafPow<4, 4, MRF_GATE_NONE, MRF_GATE_NONE>,
-                                  mrf::SLeaf<MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE, 1, MRF_GATE_NEG>,
-                                  mrf::SLeaf<MRF_FAMILY_POW, 1, MRF_GATE_NONE, 1, MRF_GATE_NEG>>;
-using LeafSetGeneric = mrf::LeafSet<mrf::LeafGeneric, mrf::SLeafGeneric, mrf::SLeafGeneric>;
-bool leaf_is(const mrf_leaf_fn& f, int family, int p, int gate) {
-  return f.family == family && f.gate == gate && (family == MRF_FAMILY_LOGISTIC || f.p == p);
-}
-bool is_panda_leafset(const mrf_config& c) {
-  return leaf_is(c.collision_geometry, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
-         leaf_is(c.collision_finsler, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
-         leaf_is(c.plane_geometry, MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE) &&
-         leaf_is(c.plane_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG) &&
-         leaf_is(c.limit_geometry, MRF_FAMILY_POW, 1, MRF_GATE_NONE) &&
-         leaf_is(c.limit_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG);
-}
-
-// the reference's rollout sphere table: the origins of panda_link1..8 (PM:25-26)
-bool is_link_origin_table(const mrf_config& c) {
-  if (c.n_spheres != 8) return false;
-  for (int s = 0; s < 8; ++s)
-    if (c.sphere_link[s] != s + 1 || c.sphere_offset[s][0] != 0.0 || c.sphere_offset[s][1] != 0.0 ||
-        c.sphere_offset[s][2] != 0.0)
-      return false;
-  return true;
-}
-
 // Cooperative (one wave per scenario) kernels pay ~5x the total work of the row-per-lane kernels but finish a
 // scenario ~4x sooner; they win while the row-per-lane grid cannot fill the chip.  cfg.kernel_select overrides.
 bool use_coop(const mrf_handle* h, int64_t n_scen) {
@@ -1028,13 +991,6 @@ bool use_coop(const mrf_handle* h, int64_t n_scen) {
   if (h->cfg.kernel_select == 1) return false;
   if (h->cfg.kernel_select == 2) return true;
   return n_scen <= h->coop_max_scen;
-}
-
-template <typename F>
-int dispatch(mrf_handle* h, F f) {
-  const bool fast = is_panda_leafset(h->cfg);
-  if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafSetPanda{}) : f(double{}, LeafSetGeneric{});
-  return fast ? f(float{}, LeafSetPanda{}) : f(float{}, LeafSetGeneric{});
 }
 
 template <bool ROLLOUT>
@@ -1169,6 +1125,7 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
 void mrf_destroy(mrf_handle* h) {
   if (!h) return;
   mrf_host::DeviceGuard guard(h->dcfg ? h->device : -1);
+  mrf_host::comm_release(h);
   if (h->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)h->graph_exec);
   if (h->own_stream) (void)hipStreamDestroy((hipStream_t)h->own_stream);
   if (h->dcfg) (void)hipFree(h->dcfg);
@@ -1316,6 +1273,14 @@ int mrf_step_predict(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t
 
 int mrf_step_action(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
                     void* qdot_io, const void* params, const void* sph_all, void* sumsq_io, void* stream) {
+  return mrf_host::step_action_slots(h, n_scen, robot_first, robot_count, q, qdot_io, params, sph_all, nullptr, sumsq_io, stream);
+}
+
+}  // extern "C"
+
+int mrf_host::step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
+                                void* qdot_io, const void* params, const void* sph_all, const int32_t* robot_slot,
+                                void* sumsq_io, void* stream) {
   MRF_CHECK_READY(h);
   if (h->cfg.model != MRF_MODEL_PANDA7 || h->cfg.mode != MRF_MODE_VEL)
     return fail(h, MRF_E_CONFIG, "sharded rollout needs the panda7 model in mode 'vel'");
@@ -1326,13 +1291,13 @@ int mrf_step_action(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t 
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = n_scen * robot_count;
   dim3 block(256), grid((unsigned)((rows + 255) / 256));
+  mrf::RobotSlots slots;
+  for (int j = 0; j < MRF_MAX_ROBOTS; ++j) slots.s[j] = robot_slot ? robot_slot[j] : j;
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
     return launch(h, mrf::k_step_action<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
                   (int)robot_first, (int)robot_count, (const T*)q, (T*)qdot_io, (const T*)params, (const T*)sph_all,
-                  (T*)sumsq_io);
+                  slots, (T*)sumsq_io);
   });
 }
-
-}  // extern "C"

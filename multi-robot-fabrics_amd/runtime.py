@@ -182,6 +182,17 @@ class FabricHandle:
         """Spheres per robot in the sharded exchange buffers (coincident link origins travel once)."""
         return int(self.lib.mrf_exchange_spheres(self._h))
 
+    def step_prepare(self, n_scen, robot_first, robot_count, q, qdot, params, stream=None):
+        """-> params with the RF-CV goal estimate applied for the owned robots in cfg.goal_estimate_mask."""
+        rows = n_scen * robot_count
+        out = torch.empty_like(params)
+        rc = self.lib.mrf_step_prepare(self._h, n_scen, robot_first, robot_count, self._arg(q, (self.dof, rows), "q"),
+                                       self._arg(qdot, (self.dof, rows), "qdot"),
+                                       self._arg(params, (abi.NPARAM, rows), "params"), self._arg(out),
+                                       self._stream(stream))
+        self._check(rc)
+        return out
+
     def step_predict(self, n_scen, robot_first, robot_count, q_io, qdot, sph_own, stream=None):
         rows = n_scen * robot_count
         S = self.exchange_spheres
@@ -202,6 +213,59 @@ class FabricHandle:
                                       self._arg(sumsq_io, (rows,), "sumsq_io"), self._stream(stream))
         self._check(rc)
 
+
+    # ------------------------------------------------------------------ robot-sharded rollout inside the library
+    def comm_unique_id(self):
+        """Rank 0 of a robot group: a fresh RCCL communicator id (bytes) to hand to every rank's comm_init_rccl."""
+        buf = (C.c_ubyte * abi.COMM_ID_BYTES)()
+        rc = self.lib.mrf_comm_unique_id(buf)
+        if rc != 0:
+            raise MrfError("mrf_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf)
+
+    def comm_init_rccl(self, rank, world, unique_id=None):
+        """RCCL transport (ncclAllGather per rollout step, issued from C++ on the caller's stream)."""
+        uid = None if unique_id is None else (C.c_ubyte * abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self.lib.mrf_comm_init(self._h, rank, world, uid))
+
+    def comm_peer_open(self, rank, world, max_scenarios):
+        """PEER transport, phase 1: allocates the exchange buffer, returns this rank's IPC handle (bytes)."""
+        buf = (C.c_ubyte * abi.IPC_HANDLE_BYTES)()
+        self._check(self.lib.mrf_comm_peer_open(self._h, rank, world, int(max_scenarios), buf))
+        return bytes(buf)
+
+    def comm_peer_connect(self, handles):
+        """PEER transport, phase 2: `handles` = every rank's IPC handle in rank order."""
+        blob = b"".join(handles)
+        self._check(self.lib.mrf_comm_peer_connect(self._h, (C.c_ubyte * len(blob)).from_buffer_copy(blob)))
+
+    def comm_partition(self):
+        first, count = C.c_int32(), C.c_int32()
+        if self.lib.mrf_comm_partition(self._h, C.byref(first), C.byref(count)) != 0:
+            raise MrfError("no communicator")
+        return first.value, count.value
+
+    def rollout_sharded(self, q_io, qdot_io, params, stream=None):
+        """H rollout steps of the owned robots with the per-step exchange inside the library; q_io / qdot_io
+        [7, n_scen*count] advance in place -> avg_vel [n_scen*count]."""
+        first, count = self.comm_partition()
+        rows = q_io.shape[1]
+        if rows % count:
+            raise MrfError("rows must be a multiple of the owned robot count")
+        avg = torch.empty((rows,), dtype=self.dtype, device=self.device)
+        rc = self.lib.mrf_rollout_sharded(self._h, rows // count, self._arg(q_io, (self.dof, rows), "q_io"),
+                                          self._arg(qdot_io, (self.dof, rows), "qdot_io"),
+                                          self._arg(params, (abi.NPARAM, rows), "params"), self._arg(avg),
+                                          self._stream(stream))
+        self._check(rc)
+        return avg
+
+    def comm_status(self):
+        """Synchronises the last sharded rollout; raises if a peer exchange timed out."""
+        self._check(self.lib.mrf_comm_status(self._h))
+
+    def comm_destroy(self):
+        self.lib.mrf_comm_destroy(self._h)
 
     # ------------------------------------------------------------------ device-resident control step (include/mrf.h)
     def control_prepare(self, q, qdot, params_nominal, params_work, apply_estimate=True, stream=None):

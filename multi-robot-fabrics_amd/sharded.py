@@ -8,6 +8,14 @@ predicted collision-sphere states after every rollout step (the excha
         all_gather         over the G ranks of the replica (RCCL over xGMI on GPUs; gloo in the CPU tests)
         mrf_step_action    fabric solve of the owned robots against everybody else's spheres; qdot := action
 
+Three transports for the exchange:
+    "torch"  the per-step loop in Python with torch.distributed.all_gather_into_tensor (gloo in the CPU tests of the
+             partitioning logic, nccl = RCCL on GPUs) -- the fallback;
+    "rccl"   mrf_rollout_sharded with the communicator inside the library: the H-step loop and the ncclAllGather calls
+             are issued from C++ on one stream (include/mrf.h); torch.distributed only carries the 128-byte id;
+    "peer"   mrf_rollout_sharded over peer-mapped exchange buffers: one persistent kernel per rollout, device-side stores
+             into the peers' memory and flag polling; torch.distributed only carries the 64-byte IPC handles.
+
 The collective moves SX*9*B scalars per owned robot per step, SX = mrf_exchange_spheres (6 for the reference's 8
 link-origin spheres: the origins of links 1/2 and 5/6 coincide and travel once; B=1: 432 B in f64), so at small B it is latency-bound;
 batching scenarios is what makes the link time matter.  The compute backend is injectable so that the
@@ -46,6 +54,9 @@ class HipStepBackend:
         self.dtype, self.device = self.h.dtype, self.h.device
         self.exchange_spheres = self.h.exchange_spheres      # 6 of the 8 link-origin spheres: two pairs coincide
 
+    def prepare(self, n_scen, first, count, q, qd, prm):
+        return self.h.step_prepare(n_scen, first, count, q, qd, prm)
+
     def predict(self, n_scen, first, count, q_io, qd, sph_own):
         self.h.step_predict(n_scen, first, count, q_io, qd, sph_own)
 
@@ -54,7 +65,7 @@ class HipStepBackend:
 
 
 class ShardedRollout:
-    def __init__(self, cfg, rank, world, backend=None, device_index=0):
+    def __init__(self, cfg, rank, world, backend=None, device_index=0, transport="torch", max_scenarios=None):
         self.cfg = cfg.copy()
         self.N, self.S, self.H = cfg.n_robots, cfg.n_spheres, cfg.horizon
         self.rank, self.world = rank, world
@@ -81,6 +92,26 @@ class ShardedRollout:
             for g, (f, c) in enumerate(self.parts):
                 idx += [g * self.cnt_max + l for l in range(c)]
             self._unpad = torch.tensor(idx, device=self.device)
+        self.transport = transport
+        if transport not in ("torch", "rccl", "peer"):
+            raise ValueError("transport must be 'torch', 'rccl' or 'peer'")
+        if transport != "torch":
+            h = self.backend.h      # the C handle owns the communicator; only its bootstrap blob travels through torch
+            if transport == "rccl":
+                box = [h.comm_unique_id() if self.grank == 0 else None]
+                if self.G > 1:
+                    dist.broadcast_object_list(box, src=self.replica * self.G, group=self.group)
+                h.comm_init_rccl(self.grank, self.G, box[0])
+            else:
+                if max_scenarios is None:
+                    raise ValueError("transport 'peer' needs max_scenarios (capacity of the exchange buffers)")
+                mine = h.comm_peer_open(self.grank, self.G, max_scenarios)
+                handles = [mine]
+                if self.G > 1:
+                    handles = [None] * self.G
+                    dist.all_gather_object(handles, mine, group=self.group)
+                h.comm_peer_connect(handles)
+            assert h.comm_partition() == (self.first, self.count)
 
     def own_rows(self, n_scen):
         """Global row indices (scenario*N + robot) of the rows this rank owns, in its local row order."""
@@ -91,12 +122,16 @@ class ShardedRollout:
     def rollout(self, q, qd, prm):
         """q, qd [7, B*count], prm [29, B*count] for the owned robots (local row = scenario*count + l).
         Advances q, qd in place over the horizon; returns avg_vel [B*count]."""
+        if self.transport != "torch":
+            return self.backend.h.rollout_sharded(q, qd, prm)
         n_scen = q.shape[1] // self.count
         S, H = self.S, self.H
         sph_pad = torch.zeros((self.G, self.cnt_max, S, 9, n_scen), dtype=self.dtype, device=self.device)
         sph_own = sph_pad[self.grank] if self.G == 1 else torch.zeros((self.cnt_max, S, 9, n_scen), dtype=self.dtype,
                                                                         device=self.device)
         sumsq = torch.zeros((n_scen * self.count,), dtype=self.dtype, device=self.device)
+        if (self.cfg.goal_estimate_mask >> self.first) & ((1 << self.count) - 1):
+            prm = self.backend.prepare(n_scen, self.first, self.count, q, qd, prm)     # RF-CV goal estimate (EXC:355-357)
         for _ in range(H):
             self.backend.predict(n_scen, self.first, self.count, q, qd, sph_own[:self.count])
             if self.G > 1:
@@ -111,8 +146,9 @@ class ShardedRollout:
     @staticmethod
     def bench(cfg, batch, args, rank, world, local_rank):
         import numpy as np
-        sr = ShardedRollout(cfg, rank, world, device_index=local_rank)
         B = args.scenarios
+        transport = getattr(args, "transport", "rccl")
+        sr = ShardedRollout(cfg, rank, world, device_index=local_rank, transport=transport, max_scenarios=B)
         rows = sr.own_rows(B).numpy()
         h = sr.backend.h
         q0, qd0, prm = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
@@ -131,9 +167,11 @@ class ShardedRollout:
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        if transport != "torch":
+            h.comm_status()          # a timed-out peer exchange raises here
         assert torch.isfinite(avg).all()
         N, H, S = cfg.n_robots, cfg.horizon, sr.S
         sb = 8 if cfg.scalar == abi.F64 else 4
@@ -149,4 +187,26 @@ class ShardedRollout:
                        "exchanged_spheres_per_robot": S},
             "rollout_steps_per_s": rate * N * H,
             "allgather_bytes_per_rank_per_step": sr.cnt_max * S * 9 * B * sb,
+            "transport": transport,
+            "roofline": ShardedRollout.roofline(cfg, sr, B, sb, elapsed / args.steps),
         }
+
+    @staticmethod
+    def roofline(cfg, sr, B, sb, seconds_per_rollout):
+        """Two views of one robot-sharded rollout (H exchange steps).  Link view: on the xGMI mesh every rank sends its
+        sphere block to each of the G-1 peers over a separate link, so one directed link carries cnt_max*SX*9*B scalars
+        per step (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU).  HBM view: SURVEY 8d's algorithmic bytes per
+        rollout-step -- here the exchanged formulation is what actually runs (spheres do go through memory)."""
+        N, H, S = cfg.n_robots, cfg.horizon, sr.S
+        link_bytes = sr.cnt_max * S * 9 * B * sb if sr.G > 1 else 0
+        per_step = seconds_per_rollout / H
+        alg = sb * (28 + 9 * S + 9 * S * (N - 1)) + sb * 23 / H            # per (robot, horizon step)
+        hbm = alg * sr.count * B / per_step                                # this rank's rows
+        out = {"bound": "xgmi_link" if sr.G > 1 else "hbm",
+               "hbm_algorithmic": {"achieved": hbm / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8.0e12,
+                                   "bytes_per_unit": alg},
+               "link": {"bytes_per_link_per_step": link_bytes, "achieved": link_bytes / per_step / 1e9, "peak": 153.0,
+                        "unit": "GB/s", "frac": link_bytes / per_step / 153e9, "steps": H}}
+        top = out["link"] if sr.G > 1 else out["hbm_algorithmic"]
+        out.update(achieved=top["achieved"], peak=top["peak"], unit="GB/s", frac=top["frac"], traffic=None)
+        return out

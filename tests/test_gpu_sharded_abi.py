@@ -1,0 +1,88 @@
+"""Robot-sharded rollout through the C ABI (include/mrf.h: mrf_comm_* / mrf_rollout_sharded).
+
+ * world 1: the RCCL transport with a real one-rank communicator (ncclCommInitRank / ncclAllGather issued from C++ on
+   the caller's stream) and the PEER transport on its own buffers, both against the fused kernel (mrf_rollout);
+ * world 2 on ONE GPU: two processes share the device, the PEER transport exchanges through IPC-mapped memory with
+   device-side flags -- even (1+1 of 2 robots) and uneven (2+1 of 3) robot blocks, link-origin and offset sphere tables.
+The multi-GPU RCCL path (world > 1) cannot run on the single-GPU test box; its partition / padding logic is the same
+code as world 1 plus the slot map covered by the uneven case of tests/test_sharded_gloo.py.
+Tolerance: identical arithmetic on identical inputs, different kernels -> f64 <= 1e-9 relative (as every parity test)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.runtime import FabricHandle, MrfError
+from multi_robot_fabrics_amd.sharded import ShardedRollout
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer"])
+@pytest.mark.parametrize("n_robots,horizon,n_scen,table", [(3, 6, 37, "lo"), (2, 5, 130, "lo"), (3, 4, 21, "offsets")])
+def test_world1_matches_fused_rollout(transport, n_robots, horizon, n_scen, table):
+    cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+    cfg.goal_estimate_mask = 0b110 & ((1 << n_robots) - 1)
+    if table == "offsets":
+        links, offs = config.sphere_offsets_per_link(2)
+        config.set_spheres(cfg, links, offs, [0.06] * len(links))
+    batch = scenarios.panda_batch(cfg, n_scen, seed=5)
+    sr = ShardedRollout(cfg, 0, 1, device_index=0, transport=transport, max_scenarios=n_scen)
+    h = sr.backend.h
+    assert h.comm_partition() == (0, n_robots)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    want_avg, tq, tqd = FabricHandle(cfg, 0).rollout(q, qd, prm, want_traj=True)
+    for _ in range(2):
+        qq, qqd = q.clone(), qd.clone()
+        avg = sr.rollout(qq, qqd, prm)
+        h.comm_status()
+        assert rel(avg, want_avg) < 1e-9 and rel(qq, tq[-1]) < 1e-9 and rel(qqd, tqd[-1]) < 1e-9
+
+
+def test_comm_argument_errors():
+    cfg = config.panda_config(n_robots=2, horizon=3)
+    h = FabricHandle(cfg, 0)
+    q = torch.zeros((7, 2), dtype=torch.float64, device="cuda")
+    with pytest.raises(MrfError):
+        h.comm_partition()                                   # no communicator yet
+    with pytest.raises(MrfError):
+        h.comm_init_rccl(0, 3)                               # more ranks than robots
+    with pytest.raises(MrfError):
+        h.comm_init_rccl(0, 2, None)                         # world > 1 needs an id
+    h.comm_peer_open(0, 1, 4)
+    with pytest.raises(MrfError):
+        h.comm_peer_open(0, 1, 4)                            # already has one
+    prm = torch.zeros((abi.NPARAM, 2 * 9), dtype=torch.float64, device="cuda")
+    with pytest.raises(MrfError):
+        h.rollout_sharded(torch.zeros((7, 18), dtype=torch.float64, device="cuda"),
+                          torch.zeros((7, 18), dtype=torch.float64, device="cuda"), prm)   # 9 scenarios > capacity 4
+    h.comm_destroy()
+    h.comm_init_rccl(0, 1)                                   # group of one without RCCL
+    assert h.comm_partition() == (0, 2)
+
+
+@pytest.mark.parametrize("n_robots,horizon,n_scen,table,dtype", [(2, 8, 50, "lo", "f64"), (3, 6, 45, "lo", "f64"),
+                                                                  (3, 4, 30, "offsets", "f64"), (2, 6, 40, "lo", "f32")])
+def test_two_processes_one_gpu_peer_exchange(n_robots, horizon, n_scen, table, dtype):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "sharded_worker.py"), str(n_robots),
+           str(horizon), str(n_scen), table, dtype]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    ranks = json.loads(line)["ranks"]
+    assert sorted(r["count"] for r in ranks) == sorted([n_robots // 2, n_robots - n_robots // 2])
+    tol = 1e-9 if dtype == "f64" else 2e-3
+    for r in ranks:
+        assert r["err"] < tol, ranks

@@ -30,6 +30,17 @@ class OracleStepBackend:
         out[:, idx] = rows_local
         return out, idx
 
+    def prepare(self, n_scen, first, count, q, qd, prm):
+        """RF-CV goal estimate x_ee + T v_ee (EXC:355-357) for the owned robots in the mask."""
+        qf, idx = self._full(n_scen, first, count, q.numpy())
+        qdf, _ = self._full(n_scen, first, count, qd.numpy())
+        x, v, _ = self.o.fk_spheres(self.cfg, qf, qdf)          # sphere 7 of the link-origin table = panda_link8 = hand
+        out = prm.clone()
+        for k, r in enumerate(idx):
+            if (self.cfg.goal_estimate_mask >> (first + k % count)) & 1:
+                out[0:3, k] = torch.from_numpy(x[7, :, r] + self.cfg.goal_estimate_T * v[7, :, r])
+        return out
+
     def predict(self, n_scen, first, count, q_io, qd, sph_own):
         q_io += self.cfg.dt * qd
         qf, idx = self._full(n_scen, first, count, q_io.numpy())
@@ -76,6 +87,7 @@ def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+        cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1      # RF-CV
         batch = scenarios.panda_batch(cfg, n_scen, seed=77, x_min=0.08)
         sr = sharded.ShardedRollout(cfg, rank, world, backend=OracleStepBackend(cfg))
         rows = sr.own_rows(n_scen).numpy()
@@ -99,6 +111,7 @@ def test_sharded_rollout_world2_matches_fused(oracle, tmp_path, n_robots):
     world, H, B = 2, 4, 5
     mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path)), nprocs=world, join=True)
     cfg = config.panda_config(n_robots=n_robots, horizon=H)
+    cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1
     batch = scenarios.panda_batch(cfg, B, seed=77, x_min=0.08)
     want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
     seen = []
