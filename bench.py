@@ -147,6 +147,28 @@ def parity_spot_check(cfg_roll, cfg_act, batch, avg, act, n_scen=64, tol=1e-9):
             "against": "oracle/mrf_oracle.cpp (float64 CPU restatement) on the first scenarios of the timed batch"}
 
 
+def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
+    """Secondary block of the default run: the north-star partitioning (robots of a scenario spread over the GPUs of a
+    group, per-step exchange of predicted sphere states) on the same batch, rollout only, for both
+    transports of include/mrf.h.  At world 1 the group is one GPU (no link traffic): it prices the exchanged
+    formulation's kernels against the fused one.  Never fatal: a transport that cannot be set up is reported as text."""
+    import copy
+    from multi_robot_fabrics_amd.sharded import ShardedRollout
+    out = {}
+    a = copy.copy(args)
+    a.steps, a.warmup = max(1, min(args.steps, 10)), 1
+    for transport in ("rccl", "peer"):
+        a.transport = transport
+        try:
+            r = ShardedRollout.bench(cfg_roll, batch, a, rank, world, local_rank)
+            out[transport] = {k: r[k] for k in ("value", "unit", "ms_per_step", "rollout_steps_per_s", "steps",
+                                                "allgather_bytes_per_rank_per_step", "parity_vs_fused_kernel", "roofline")}
+            out[transport]["config"] = r["config"]
+        except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
+            out[transport] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    return out
+
+
 def single_scenario_latency(h_roll, h_act, batch, N, S, iters=200):
     """B = 1: what a real-time controller of one N-Panda cell sees per control step, action copied back to the host."""
     q, qd, prm = (h_roll.tensor(batch[k][:, :N]) for k in ("q", "qdot", "params"))
@@ -182,7 +204,18 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "peer", "torch"], default="rccl",
                     help="--shard robots: exchange inside the library over RCCL (default) or peer-mapped buffers, or the Python loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-robot-shard", action="store_true", help="skip the secondary robot-sharded block of the default run")
     args = ap.parse_args()
+
+    # Only the JSON line may reach stdout: libraries print banners there (RCCL's version block on communicator
+    # creation), so file descriptor 1 points at stderr while the run is in progress and the line goes to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,9 +260,11 @@ def main():
     if args.shard == "robots":
         from multi_robot_fabrics_amd.sharded import ShardedRollout
         args.scenarios = B
-        result = ShardedRollout.bench(cfg_roll, batch, args, rank, world, local_rank)
+        result = ShardedRollout.bench(cfg_roll, batch if world == 1 else None, args, rank, world, local_rank)
         if rank == 0:
-            print(json.dumps(result))
+            emit(result)
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
 
     h_roll = FabricHandle(cfg_roll, local_rank)
@@ -265,6 +300,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(avg).all() and torch.isfinite(act).all()
+
+    sharded_block = None
+    if not args.no_robot_shard and not share_gpu:
+        args.scenarios = B
+        sharded_block = robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank)
 
     if rank == 0:
         roll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -320,11 +360,13 @@ def main():
             "roofline": roofline,
         }
         out["parity_spot_check"] = parity_spot_check(cfg_roll, cfg_act, batch, avg, act)
+        if sharded_block is not None:
+            out["robot_sharded"] = sharded_block
         if world == 1:
             out["single_scenario"] = single_scenario_latency(h_roll, h_act, batch, N, S)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_roll, cfg_act, batch)
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -192,6 +192,10 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
               }
             }
           }
+          if (V.G == 1) {  // a group of one: the only reader of these stores is this very wave
+            __syncthreads();
+            return;
+          }
           __threadfence_system();  // the wave's stores (local and remote) are performed before the flags go up
           __syncthreads();
           if (lane < V.G)

@@ -96,21 +96,51 @@ class ShardedRollout:
         if transport not in ("torch", "rccl", "peer"):
             raise ValueError("transport must be 'torch', 'rccl' or 'peer'")
         if transport != "torch":
-            h = self.backend.h      # the C handle owns the communicator; only its bootstrap blob travels through torch
+            # The C handle owns the communicator; only its bootstrap blob travels through torch.  A rank whose local
+            # setup fails still takes part in every collective below (with an error marker), so that the whole group
+            # raises together instead of leaving the healthy ranks waiting.
+            h = self.backend.h
+            err = None
             if transport == "rccl":
-                box = [h.comm_unique_id() if self.grank == 0 else None]
+                box = [None]
+                if self.grank == 0:
+                    try:
+                        box = [h.comm_unique_id()]
+                    except Exception as e:       # noqa: BLE001
+                        box = ["ERR " + str(e)]
                 if self.G > 1:
                     dist.broadcast_object_list(box, src=self.replica * self.G, group=self.group)
-                h.comm_init_rccl(self.grank, self.G, box[0])
+                if isinstance(box[0], str):
+                    err = box[0]
+                else:
+                    try:
+                        h.comm_init_rccl(self.grank, self.G, box[0])
+                    except Exception as e:       # noqa: BLE001
+                        err = str(e)
             else:
                 if max_scenarios is None:
                     raise ValueError("transport 'peer' needs max_scenarios (capacity of the exchange buffers)")
-                mine = h.comm_peer_open(self.grank, self.G, max_scenarios)
+                try:
+                    mine = h.comm_peer_open(self.grank, self.G, max_scenarios)
+                except Exception as e:           # noqa: BLE001
+                    mine, err = None, str(e)
                 handles = [mine]
                 if self.G > 1:
                     handles = [None] * self.G
                     dist.all_gather_object(handles, mine, group=self.group)
-                h.comm_peer_connect(handles)
+                if any(x is None for x in handles):
+                    err = err or "a peer could not allocate / export its exchange buffer"
+                else:
+                    try:
+                        h.comm_peer_connect(handles)
+                    except Exception as e:       # noqa: BLE001
+                        err = str(e)
+            if self.G > 1:
+                errs = [None] * self.G
+                dist.all_gather_object(errs, err, group=self.group)
+                err = next((e for e in errs if e), None)
+            if err:
+                raise RuntimeError(f"robot-group transport '{transport}' could not be set up: {err}")
             assert h.comm_partition() == (self.first, self.count)
 
     def own_rows(self, n_scen):
@@ -149,6 +179,10 @@ class ShardedRollout:
         B = args.scenarios
         transport = getattr(args, "transport", "rccl")
         sr = ShardedRollout(cfg, rank, world, device_index=local_rank, transport=transport, max_scenarios=B)
+        if world > 1 or batch is None:
+            # the ranks of one robot group work on the SAME scenarios (one batch per replica)
+            from . import scenarios
+            batch = scenarios.panda_batch(cfg, B, seed=1000 + sr.replica)
         rows = sr.own_rows(B).numpy()
         h = sr.backend.h
         q0, qd0, prm = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
@@ -173,6 +207,18 @@ class ShardedRollout:
         if transport != "torch":
             h.comm_status()          # a timed-out peer exchange raises here
         assert torch.isfinite(avg).all()
+        # parity of the sharded result with the fused single-GPU kernel on the first scenarios of the replica's batch
+        from .runtime import FabricHandle
+        nchk = min(B, 64)
+        ref = FabricHandle(cfg, local_rank)
+        fq, fqd, fprm = (ref.tensor(np.ascontiguousarray(batch[k][:, :nchk * cfg.n_robots])) for k in ("q", "qdot", "params"))
+        want = ref.rollout(fq, fqd, fprm)[sr.own_rows(nchk).to(ref.device)]
+        got = avg[:nchk * sr.count]
+        perr = float((got - want).abs().max() / want.abs().max().clamp_min(1e-300))
+        if world > 1:
+            t = torch.tensor([perr], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            perr = float(t.item())
         N, H, S = cfg.n_robots, cfg.horizon, sr.S
         sb = 8 if cfg.scalar == abi.F64 else 4
         rate = sr.D * B * args.steps / elapsed
@@ -188,6 +234,8 @@ class ShardedRollout:
             "rollout_steps_per_s": rate * N * H,
             "allgather_bytes_per_rank_per_step": sr.cnt_max * S * 9 * B * sb,
             "transport": transport,
+            "parity_vs_fused_kernel": {"max_rel_err": perr, "tol": 1e-9 if cfg.scalar == abi.F64 else 2e-3,
+                                       "ok": perr <= (1e-9 if cfg.scalar == abi.F64 else 2e-3), "scenarios": nchk},
             "roofline": ShardedRollout.roofline(cfg, sr, B, sb, elapsed / args.steps),
         }
 

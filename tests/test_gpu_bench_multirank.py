@@ -46,3 +46,21 @@ def test_bare_launch_spawns_its_own_ranks():
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["scenarios_per_gpu"] == 2016
+
+
+def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
+    """bench.py --shard robots over the PEER transport with the two ranks of the robot group sharing the one GPU: the
+    JSON line carries the link / algorithmic-HBM roofline views and the sharded result agrees with the fused kernel."""
+    env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenarios", "2016",
+           "--shard", "robots", "--transport", "peer"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["transport"] == "peer"
+    assert r["config"]["robot_group_ranks"] == 2 and r["config"]["robots_per_rank"] == [2, 1]
+    assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]
+    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 2 * 6 * 9 * 2016 * 8
+    assert r["allgather_bytes_per_rank_per_step"] == 2 * 6 * 9 * 2016 * 8
