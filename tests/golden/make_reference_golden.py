@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Reference-side pin of the fabric solve: evaluates the REAL reference stack on the seeded inputs of the committed
+golden files and writes the outputs next to them.
+
+    python tests/golden/make_reference_golden.py [--reference /path/to/multi-robot-fabrics]
+
+Needs an environment in which the reference itself runs (its pyproject.toml pins: python >=3.8,<3.10,
+fabrics==0.9.5, forwardkinematics==1.2.3, casadi==3.5.5, mpscenes, quaternionic, matplotlib).  None of those is
+importable in the build container, so this script has never run there: it is the one command that turns
+"parity unpinned" into "pinned" for anyone who has the wheels.  It reads INPUTS from
+    tests/golden/panda_actions.npz, planar_actions.npz, panda_rollout.npz        (made by make_golden.py)
+and writes data only (no reference source) to
+    tests/golden/reference_panda_actions.npz     action [cases,7]        planner.compute_action(**kwargs)
+    tests/golden/reference_planar_actions.npz    action [cases,3]
+    tests/golden/reference_panda_rollout.npz     {dyn,stat}_{q,qd}[2,H,7], {dyn,stat}_avg[2]
+As soon as those files exist, tests/test_reference_pin.py (CPU: the oracle; -m gpu: the HIP kernels) compares against
+them instead of skipping, and tests/reconcile_constants.py fits the recalled constants of mrf_config to them.
+
+The planners are built call by call as the reference's drivers build them:
+    Panda        examples/example_pandas_Jointspace.py:64-134  (set_planner_panda), kwargs of :421-439
+    rollouts     examples/example_pandas_Jointspace.py:172-193 (define_rollout_planners), :354-375 (inputs_action),
+                 multi_robot_fabrics/fabrics_planner/forward_planner_Jointspace.py:298-423
+    point robot  examples/example_pointmasses_static.py:102-129 (set_planner_point), kwargs of :191-199
+The only liberty: the mount transform T_0 and the obstacle counts come from the golden case instead of from
+parameters_manipulators (set_mount_transformation / set_components take them as plain arguments anyway).
+"""
+import argparse
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def need(mod):
+    try:
+        return __import__(mod)
+    except Exception as e:  # noqa: BLE001
+        sys.exit("cannot import %r (%s).\nThis script needs the reference's own environment: python<3.10 with "
+                 "fabrics==0.9.5 forwardkinematics==1.2.3 casadi==3.5.5 mpscenes quaternionic matplotlib." % (mod, e))
+
+
+def panda_goal(GoalComposition, n_goals=3):
+    """create_dummy_goal_panda (EXJ:25-62); the values are placeholders, the runtime kwargs carry the real ones."""
+    goal_dict = {
+        "subgoal0": {"weight": 2.0, "is_primary_goal": True, "indices": [0, 1, 2], "parent_link": "world",
+                     "child_link": "panda_hand", "desired_position": [0.1, 0.6, 0.8], "epsilon": 0.05,
+                     "type": "staticSubGoal"},
+        "subgoal1": {"weight": 10.0, "is_primary_goal": False, "indices": [0, 1, 2], "parent_link": "panda_link7",
+                     "child_link": "panda_hand", "desired_position": [0.107, 0.0, 0.0],
+                     "angle": [-0.366, 0.0, 0.0, 0.3305], "epsilon": 0.05, "type": "staticSubGoal"},
+        "subgoal2": {"weight": 1.0, "is_primary_goal": False, "indices": [6], "desired_position": [math.pi / 4],
+                     "epsilon": 0.05, "type": "staticJointSpaceSubGoal"},
+    }
+    keep = ["subgoal0", "subgoal1", "subgoal2"][:n_goals]
+    return GoalComposition(name="goal", content_dict={k: goal_dict[k] for k in keep})
+
+
+def set_planner_panda(mods, urdf, T_0, nr_obst, nr_obst_dyn, collision_links_nr, with_goal=True):
+    """EXJ:64-134 with the mount transform passed in."""
+    fk = mods["GenericURDFFk"](urdf, "panda_link0", "panda_leftfinger")
+    planner = mods["ParameterizedFabricPlanner"](
+        7, fk,
+        geometry_plane_constraint="10*(1/(1+1*ca.exp(-10*x))-1) * (xdot**2)",
+        collision_geometry="-0.5 / (x ** 4) * (xdot ** 2)",
+        collision_finsler="0.01/(x**4) * xdot**2",
+    )
+    collision_links = ["panda_link%d" % l if l < 9 else "panda_hand" for l in collision_links_nr]
+    panda_limits = [[-2.8973, 2.8973], [-1.7628, 1.7628], [-2.8973, 2.8973], [-3.0718, -0.0698], [-2.8973, 2.8973],
+                    [-0.0175, 3.7525], [-2.8973, 2.8973]]
+    planner._forward_kinematics.set_mount_transformation(np.array(T_0))
+    goal = panda_goal(mods["GoalComposition"]) if with_goal else None
+    planner.set_components(collision_links=collision_links, goal=goal, number_obstacles=nr_obst,
+                           number_dynamic_obstacles=nr_obst_dyn, dynamic_obstacle_dimension=3,
+                           number_plane_constraints=1, limits=panda_limits)
+    planner.concretize(mode="vel", time_step=0.01)
+    return planner, goal
+
+
+R1 = np.array([[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]])
+
+
+def panda_actions(mods, urdf):
+    g = np.load(os.path.join(HERE, "panda_actions.npz"))
+    out = []
+    for ci, kind in enumerate(g["kinds"]):
+        kind = str(kind)
+        M = g["ox"].shape[1]
+        static = kind == "static"
+        grasp = kind == "grasp"
+        planner, _ = set_planner_panda(mods, urdf, g["mount"][ci], nr_obst=M if static else 0,
+                                       nr_obst_dyn=0 if (static or grasp) else M,
+                                       collision_links_nr=[] if grasp else [1, 2, 3, 4, 5, 6, 7, 8],
+                                       with_goal=kind != "nogoal")
+        rb = g["rb"][ci]
+        kw = dict(q=g["q"][ci], qdot=g["qd"][ci], constraint_0=np.array([0.0, 0.0, 1.0, -0.65]),
+                  radius_body_panda_links={str(l): np.array(rb[l - 3]) for l in range(3, 9)},
+                  radius_body_panda_hand=np.array([rb[5]]))
+        if kind != "nogoal":
+            kw.update(x_goal_0=g["g0"][ci], weight_goal_0=2.0, angle_goal_1=R1, x_goal_1=np.array([0.107, 0.0, 0.0]),
+                      weight_goal_1=20.0, x_goal_2=np.array([math.pi / 4]), weight_goal_2=1.0)
+        if static:
+            kw.update(x_obsts=list(g["ox"][ci]), radius_obsts=list(g["orad"][ci]))
+        elif not grasp:
+            kw.update(x_obsts_dynamic=list(g["ox"][ci]), xdot_obsts_dynamic=list(g["ov"][ci]),
+                      xddot_obsts_dynamic=list(g["oa"][ci]), radius_obsts_dynamic=list(g["orad"][ci]))
+        action = np.asarray(planner.compute_action(**kw), dtype=float).reshape(-1)
+        print("panda action", ci, kind, action)
+        out.append(action)
+    np.savez(os.path.join(HERE, "reference_panda_actions.npz"), action=np.stack(out), kinds=g["kinds"])
+
+
+def planar_actions(mods, ref_root):
+    g = np.load(os.path.join(HERE, "planar_actions.npz"))
+    with open(os.path.join(ref_root, "examples", "simulation_environments", "urdfs", "pointRobot1.urdf")) as f:
+        urdf = f.read()
+    goal = mods["GoalComposition"](name="goal", content_dict={
+        "subgoal0": {"weight": 1, "is_primary_goal": True, "indices": [0, 1], "parent_link": "world",
+                     "child_link": "base_link", "desired_position": [1.5, 0.99], "epsilon": 0.1, "type": "staticSubGoal"}})
+    out = []
+    for ci in range(len(g["q"])):
+        n_static, dyn = int(g["n_static"][ci]), int(g["dyn"][ci])
+        M = g["ox"].shape[1]
+        fk = mods["GenericURDFFk"](urdf, "world", "base_link")
+        planner = mods["ParameterizedFabricPlanner"](
+            3, fk, collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
+            collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
+        kw = dict(q=g["q"][ci], qdot=g["qd"][ci], x_goal_0=g["g0"][ci], weight_goal_0=1.0, radius_body_base_link=0.2)
+        if not dyn:          # example_pointmasses_static.py:122-128
+            planner.set_components(["base_link"], {}, goal=goal, number_obstacles=M)
+            kw.update(x_obsts=list(g["ox"][ci]), radius_obsts=list(g["orad"][ci]))
+        else:                # example_pointmasses_dynamic.py: static scene spheres + 2-D dynamic spheres
+            ns = n_static
+            planner.set_components(["base_link"], {}, goal=goal, number_obstacles=ns, number_dynamic_obstacles=M - ns,
+                                   dynamic_obstacle_dimension=2)
+            if ns:
+                kw.update(x_obsts=list(g["ox"][ci][:ns]), radius_obsts=list(g["orad"][ci][:ns]))
+            kw.update(x_obsts_dynamic=[x[:2] for x in g["ox"][ci][ns:]], xdot_obsts_dynamic=[v[:2] for v in g["ov"][ci][ns:]],
+                      xddot_obsts_dynamic=[a[:2] for a in g["oa"][ci][ns:]], radius_obsts_dynamic=list(g["orad"][ci][ns:]))
+        planner.concretize()
+        action = np.asarray(planner.compute_action(**kw), dtype=float).reshape(-1)
+        print("planar action", ci, action)
+        out.append(action)
+    np.savez(os.path.join(HERE, "reference_planar_actions.npz"), action=np.stack(out))
+
+
+def rollouts(mods, urdf):
+    """2-Panda coupled rollout H=3 through the reference's ForwardFabricsPlanner (EXJ:172-193, 354-375)."""
+    import examples.parameters_manipulators as parameters_manipulators
+    from multi_robot_fabrics.fabrics_planner.forward_planner_Jointspace import ForwardFabricsPlanner
+    from multi_robot_fabrics.utils.utils import UtilsKinematics
+    g = np.load(os.path.join(HERE, "panda_rollout.npz"))
+    H = g["dyn_q"].shape[1]
+    out = {}
+    for name, dynamic in (("dyn", 1), ("stat", 0)):
+        params = parameters_manipulators.manipulator_parameters(nr_robots=2)
+        params.define_settings(ROLLOUT_FABRICS=True, ROLLOUTS_PLOTTING=True, STATIC_OR_DYN_FABRICS=dynamic,
+                               RESOLVE_DEADLOCKS=True, ESTIMATE_GOAL=False, N_HORIZON=H)
+        planners, goal_structs = [], []
+        for i in range(2):
+            p, gs = set_planner_panda(mods, urdf, params.mount_transform[i], nr_obst=params.nr_obsts[i],
+                                      nr_obst_dyn=params.nr_obsts_dyn[i], collision_links_nr=params.collision_links_nrs[i])
+            planners.append(p)
+            goal_structs.append(gs)
+        fk_dict = UtilsKinematics().define_forward_kinematics(planners=planners, collision_links_nrs=params.collision_links_nrs,
+                                                              collision_links=params.collision_links)
+        fwd = ForwardFabricsPlanner(params=params, planners=planners, N_steps=10, fk_dict=fk_dict,
+                                    goal_struct_robots=goal_structs)
+        fwd.forward_multi_fabrics_symbolic()
+        inputs_action = {"q_robots": [g[name + "_q0"][i] for i in range(2)], "q_dot_robots": [g[name + "_qd0"][i] for i in range(2)],
+                         "x_obsts": [[] * 2], "x_goals0": [g[name + "_g0"][i] for i in range(2)],
+                         "x_goals1": [np.array([0.107, 0.0, 0.0])] * 2, "x_goals2": [np.array([math.pi / 4])] * 2,
+                         "weight_goals0": [2.0, 2.0], "weight_goals1": [20.0, 20.0], "weight_goals2": [1.0, 1.0],
+                         "constraints": [np.array([0, 0, 1, -params.z_table])] * 2}
+        avg = fwd.get_velocity_rollouts(inputs_action=inputs_action)
+        qN, qdN, _ = fwd.rollouts_numerical(inputs_action=inputs_action)
+        # rollouts_numerical returns, per robot, a one-element list holding an array [7, H] (FPJ:381-391)
+        out[name + "_q"] = np.stack([np.asarray(qN["robot_%d" % i][0]).reshape(7, H).T for i in range(2)])
+        out[name + "_qd"] = np.stack([np.asarray(qdN["robot_%d" % i][0]).reshape(7, H).T for i in range(2)])
+        out[name + "_avg"] = np.array([float(np.asarray(a).reshape(-1)[0]) for a in avg])
+        print("rollout", name, out[name + "_avg"])
+    np.savez(os.path.join(HERE, "reference_panda_rollout.npz"), **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default=os.environ.get("MRF_REFERENCE", "/root/reference"),
+                    help="checkout of tud-amr/multi-robot-fabrics (for its URDFs and its rollout classes)")
+    args = ap.parse_args()
+    ref_root = os.path.abspath(args.reference)
+    urdf_path = os.path.join(ref_root, "examples", "simulation_environments", "urdfs", "panda_with_finger.urdf")
+    if not os.path.exists(urdf_path):
+        sys.exit("reference checkout not found at %s (--reference)" % ref_root)
+    need("casadi")
+    need("fabrics")
+    need("forwardkinematics")
+    need("mpscenes")
+    sys.path.insert(0, ref_root)
+    from fabrics.planner.parameterized_planner import ParameterizedFabricPlanner
+    from forwardkinematics.urdfFks.generic_urdf_fk import GenericURDFFk
+    from mpscenes.goals.goal_composition import GoalComposition
+    mods = dict(ParameterizedFabricPlanner=ParameterizedFabricPlanner, GenericURDFFk=GenericURDFFk,
+                GoalComposition=GoalComposition)
+    with open(urdf_path) as f:
+        urdf = f.read()
+    panda_actions(mods, urdf)
+    planar_actions(mods, ref_root)
+    rollouts(mods, urdf)
+    print("wrote tests/golden/reference_{panda_actions,planar_actions,panda_rollout}.npz -- "
+          "now run: python -m pytest tests/test_reference_pin.py   and   python tests/reconcile_constants.py")
+
+
+if __name__ == "__main__":
+    main()
