@@ -1,0 +1,41 @@
+"""examples/example_pandas_jointspace.py end to end: the reference's eight-key YAML ->
+manipulator_parameters -> define_planners / define_rollout_planners -> the control loop through the mirrored classes
+(get_velocity_rollouts, deadlock_checking, compute_action(**kwargs)), then the same configuration as a device-resident
+episode."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_example():
+    spec = importlib.util.spec_from_file_location("example_pandas_jointspace",
+                                                  os.path.join(ROOT, "examples", "example_pandas_jointspace.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_yaml_to_planners_to_control_loop(tmp_path):
+    ex = load_example()
+    res = ex.define_run_panda_example(os.path.join(ROOT, "examples", "configs", "panda_config.yaml"), n_steps=40)
+    assert res["config"]["n_robots"] == 2 and res["config"]["N_HORIZON"] == 10 and res["config"]["n_obst_per_link"] == 4
+    assert np.isfinite(res["solver_time_ms_mean"]) and res["solver_time_ms_mean"] < 50.0
+    assert all(np.isfinite(d) for d in res["ee_distance_to_goal_m"])
+    # host-API loop (link-origin velocities repeated per sphere, EXJ:409-410) vs device episode (per-sphere velocities):
+    # the same motion up to that modelling difference
+    assert res["host_api_vs_device_episode_max_abs_dq"] < 0.05
+
+
+def test_three_robot_config_without_rollouts(tmp_path):
+    ex = load_example()
+    cfg = tmp_path / "c.yaml"
+    cfg.write_text("n_robots: 3\nROLLOUT_FABRICS: False\nROLLOUTS_PLOTTING: False\nSTATIC_OR_DYN_FABRICS: 0\n"
+                   "RESOLVE_DEADLOCKS: 0\nESTIMATE_GOAL: False\nN_HORIZON: 5\nn_obst_per_link: 1\n")
+    res = ex.define_run_panda_example(str(cfg), n_steps=25)
+    assert res["config"]["n_robots"] == 3 and res["time_in_deadlock_steps"] == 0
+    assert res["host_api_vs_device_episode_max_abs_dq"] < 1e-9      # static fabrics: no sphere velocities involved
