@@ -79,7 +79,7 @@ typedef struct {
   int32_t n_spheres;   /* S: exchanged spheres per robot in rollouts (reference: 8 link origins) */
   int32_t horizon;     /* H */
   int32_t dynamic;     /* STATIC_OR_DYN_FABRICS: 0 zeroes the exchanged v,a (FPJ:215-217) */
-  int32_t n_ego;       /* 6 = collision+plane leaves on links 3..8; 0 = "grasp" planner (EXJ:160-166); planar3: 1 or 0 */
+  int32_t n_ego;       /* 6 = collision+plane leaves on the links of ego_link_mask; 0 = "grasp" planner (EXJ:160-166); planar3: 1 or 0 */
   int32_t n_planes;    /* 0 or 1 plane constraint per ego point */
   int32_t use_limits;  /* joint-limit leaves on/off */
   int32_t n_goals;     /* attractors in use: panda 0..3, planar3 0..1 */
@@ -105,7 +105,9 @@ typedef struct {
   mrf_leaf_fn plane_geometry, plane_finsler;
   mrf_leaf_fn limit_geometry, limit_finsler;
   int32_t kernel_select; /* coupled kernels: 0 = auto by batch size, 1 = row-per-lane (throughput), 2 = one wave per scenario (latency) */
-  int32_t reserved0;
+  int32_t ego_link_mask; /* panda7, n_ego == 6: bit (l-3) set = panda_link l (l = 3..8) carries collision and plane leaves --
+                            the collision_links list of set_components (EXJ:91-96,123-125; the Cartesian rollout class
+                            defaults to link 7 alone, FPC:20-21).  0x3F = all six (the examples' setting). */
 } mrf_config;
 
 typedef struct mrf_handle mrf_handle;

@@ -62,7 +62,7 @@ class Config(C.Structure):
         ("collision_geometry", LeafFn), ("collision_finsler", LeafFn),
         ("plane_geometry", LeafFn), ("plane_finsler", LeafFn),
         ("limit_geometry", LeafFn), ("limit_finsler", LeafFn),
-        ("kernel_select", C.c_int32), ("reserved0", C.c_int32),
+        ("kernel_select", C.c_int32), ("ego_link_mask", C.c_int32),
     ]
 
     def copy(self):

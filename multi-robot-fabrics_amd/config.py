@@ -85,6 +85,7 @@ def _common(cfg):
     cfg.eta_a, cfg.eta_s = 0.9 * (1 - 1 / 2), 0.5
     cfg.plane_abs = 1
     cfg.zero_small_action = 1
+    cfg.ego_link_mask = 0x3F        # collision + plane leaves on all of links 3..8
 
 
 def set_strings(cfg, **strings):
@@ -110,6 +111,19 @@ def set_spheres(cfg, links, offsets=None, radii=None):
         for c in range(3):
             cfg.sphere_offset[s][c] = float(off[c])
         cfg.sphere_radius[s] = 0.08 if radii is None else float(radii[s])
+
+
+def ego_link_mask(link_numbers):
+    """Bit mask of mrf_config.ego_link_mask for a list of Panda link numbers; links 1 and 2 do not move with q, so
+    fabrics creates no leaf for them (FPJ:39,164: `coll_i > 2`) and they are dropped here too."""
+    mask = 0
+    for l in link_numbers:
+        l = int(l)
+        if l > 8:
+            l = 8                   # 'panda_hand' (EXJ:95-96) has the origin of panda_link8
+        if l > 2:
+            mask |= 1 << (l - 3)
+    return mask
 
 
 def sphere_offsets_per_link(n_obst_per_link):

@@ -39,6 +39,7 @@ struct DevCfg {
   // 1/2 and of links 5/6 coincide with identical velocity and Jdot*qdot.  When their radii are equal too, the two
   // spheres produce the same leaf twice: the coupled kernels evaluate it once with weight 2 (set by the host).
   int lo_merge01, lo_merge45;
+  int ego_mask;  // bit (l-3): panda_link l carries collision + plane leaves (mrf_config.ego_link_mask)
   T dt, eps, jsign, goal_T, base_mass;
   T attr_k, attr_alpha, attr_mu, attr_ml, attr_a;
   T beta_a, beta_r, beta_b, beta_s, eta_a, eta_s;
@@ -514,6 +515,7 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
                                                     T mult = T(1)) {  // mult: multiplicity of coincident spheres
 #pragma unroll
   for (int g = 0; g < NP; ++g) {
+    if (E.nl[g] < 1) continue;  // point without a collision link (ego_link_mask); a compile-time fact on the default set
     T dx[3] = {E.p[g][0] - xo[0], E.p[g][1] - xo[1], planar ? T(0) : E.p[g][2] - xo[2]};
     T vr[3] = {E.v[g][0] - vo[0], E.v[g][1] - vo[1], planar ? T(0) : E.v[g][2] - vo[2]};
     T d2 = dot3(dx, dx);
@@ -529,7 +531,7 @@ __device__ __forceinline__ void accumulate_obstacle(const DevCfg<T>& cfg, const 
       cl = (T(2) * mult) * cfg.cf.k * gate_value<T>(CL::gl, nv);  // sign(xd) == sign(nv), R > 0
       cgnv2 = cfg.cg.k * gate_value<T>(CL::gg, nv) * nv * nv;
     }
-    T wM, wf;  // every ego point carries at least one link (nl >= 1)
+    T wM, wf;
     collision_leaf<CL>(cfg, d, nv, ro + E.rb[g][0], curv, cl, cgnv2, wM, wf);
     if (E.nl[g] > 1) {
       T wm2, wf2;
@@ -767,8 +769,34 @@ __device__ __forceinline__ void load_state(int64_t rows, int64_t r, const T* __r
   }
 }
 
-template <typename T, class PRM>
-__device__ __forceinline__ void panda_ego_points(const PandaKin<T>& K, const PRM& prm, EgoPts<T, NG>& E) {
+// Body radii of the links that share ego point g (0: link 3, 1: link 4, 2: links 5 and 6, 3: link 7, 4: link 8).
+// MASKED = false is the examples' full set (all six links, compile-time counts); MASKED = true reads
+// cfg.ego_mask (collision_links subsets, EXJ:91-96 / FPC:20-21) and runs in the runtime-family instantiations.
+template <bool MASKED, typename T, class PRM>
+__device__ __forceinline__ void ego_point_links(const DevCfg<T>& cfg, const PRM& prm, int g, T& rb0, T& rb1, int& nl) {
+  if (g == 2) {
+    const T r5 = prm[MRF_P_RADIUS_BODY + 2], r6 = prm[MRF_P_RADIUS_BODY + 3];
+    if constexpr (MASKED) {
+      const int b5 = (cfg.ego_mask >> 2) & 1, b6 = (cfg.ego_mask >> 3) & 1;
+      rb0 = b5 ? r5 : r6;
+      rb1 = r6;
+      nl = b5 + b6;
+    } else {
+      rb0 = r5;
+      rb1 = r6;
+      nl = 2;
+    }
+    return;
+  }
+  const int e = g < 2 ? g : g + 1;  // index into radius_body / bit of the mask
+  rb0 = prm[MRF_P_RADIUS_BODY + e];
+  rb1 = T(0);
+  nl = MASKED ? ((cfg.ego_mask >> e) & 1) : 1;
+}
+
+template <bool MASKED, typename T, class PRM>
+__device__ __forceinline__ void panda_ego_points(const DevCfg<T>& cfg, const PandaKin<T>& K, const PRM& prm,
+                                                 EgoPts<T, NG>& E) {
   constexpr int jo[4] = {2, 3, 4, 6};  // joint-origin index of links 3, 4, 5(=6), 7
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -782,12 +810,8 @@ __device__ __forceinline__ void panda_ego_points(const PandaKin<T>& K, const PRM
     E.p[4][k] = K.p8[k];
     E.v[4][k] = K.v8[k];
   }
-  // body radii of links 3..8
-  E.rb[0][0] = prm[MRF_P_RADIUS_BODY + 0]; E.rb[0][1] = T(0); E.nl[0] = 1;
-  E.rb[1][0] = prm[MRF_P_RADIUS_BODY + 1]; E.rb[1][1] = T(0); E.nl[1] = 1;
-  E.rb[2][0] = prm[MRF_P_RADIUS_BODY + 2]; E.rb[2][1] = prm[MRF_P_RADIUS_BODY + 3]; E.nl[2] = 2;
-  E.rb[3][0] = prm[MRF_P_RADIUS_BODY + 4]; E.rb[3][1] = T(0); E.nl[3] = 1;
-  E.rb[4][0] = prm[MRF_P_RADIUS_BODY + 5]; E.rb[4][1] = T(0); E.nl[4] = 1;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) ego_point_links<MASKED>(cfg, prm, g, E.rb[g][0], E.rb[g][1], E.nl[g]);
 }
 
 // Everything after the obstacle loop: plane + pullbacks + limits + attractors + solves + damping.
@@ -930,7 +954,7 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
     PandaKin<T> K;
     panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K);
     EgoPts<T, NG> E;
-    panda_ego_points(K, prm, E);
+    panda_ego_points<LS::Collision::generic>(cfg, K, prm, E);
     MRF_MARK("walk");
     publish(K);
     EgoAcc<T, NG> acc;
@@ -945,7 +969,7 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
   {
     PandaKin<T> K1;
     panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K1);
-    panda_ego_points(K1, prm, E);
+    panda_ego_points<LS::Collision::generic>(cfg, K1, prm, E);
     publish(K1);  // coupled kernels: hand this robot's link states to the other lanes of the scenario
   }
   EgoAcc<T, NG> acc;

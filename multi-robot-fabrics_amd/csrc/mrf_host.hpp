@@ -72,8 +72,9 @@ using LeafSetGeneric = mrf::LeafSet<mrf::LeafGeneric, mrf::SLeafGeneric, mrf::SL
 inline bool leaf_is(const mrf_leaf_fn& f, int family, int p, int gate) {
   return f.family == family && f.gate == gate && (family == MRF_FAMILY_LOGISTIC || f.p == p);
 }
-inline bool is_panda_leafset(const mrf_config& c) {
-  return leaf_is(c.collision_geometry, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
+inline bool is_panda_leafset(const mrf_config& c) {  // ... and the examples' full collision-link set
+  return (c.n_ego == 0 || c.ego_link_mask == 0x3F) &&
+         leaf_is(c.collision_geometry, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
          leaf_is(c.collision_finsler, MRF_FAMILY_POW, 4, MRF_GATE_NONE) &&
          leaf_is(c.plane_geometry, MRF_FAMILY_LOGISTIC, 0, MRF_GATE_NONE) &&
          leaf_is(c.plane_finsler, MRF_FAMILY_POW, 1, MRF_GATE_NEG) &&

@@ -597,9 +597,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
       E1.p[0][k3] = g == 0 ? K.o[2][k3] : (g == 1 ? K.o[3][k3] : (g == 2 ? K.o[4][k3] : (g == 3 ? K.o[6][k3] : K.p8[k3])));
       E1.v[0][k3] = g == 0 ? K.vo[2][k3] : (g == 1 ? K.vo[3][k3] : (g == 2 ? K.vo[4][k3] : (g == 3 ? K.vo[6][k3] : K.v8[k3])));
     }
-    E1.rb[0][0] = P[MRF_P_RADIUS_BODY + (g < 3 ? g : g + 1)];
-    E1.rb[0][1] = P[MRF_P_RADIUS_BODY + 3];
-    E1.nl[0] = g == 2 ? 2 : 1;
+    ego_point_links<LS::Collision::generic>(cfg, P, g, E1.rb[0][0], E1.rb[0][1], E1.nl[0]);
     EgoAcc<T, 1> a1;
     a1.zero();
     if (cfg.n_ego > 0) {
@@ -638,7 +636,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
       for (int e = 0; e < 3; ++e) acc.b[gg][e] = __shfl(a1.b[0][e], srcl);
     }
     EgoPts<T, NG> E;
-    panda_ego_points(K, P, E);
+    panda_ego_points<LS::Collision::generic>(cfg, K, P, E);
     T qdd[7], act[7];
     panda_finish_row<LS, true>(cfg, R, P, K, E, acc, qdd, act);
     if (COOP_ROLLOUT) {
@@ -901,6 +899,7 @@ void to_dev_cfg(const mrf_config& c, mrf::DevCfg<T>& d) {
   d.horizon = c.horizon; d.dynamic = c.dynamic; d.n_ego = c.n_ego; d.n_planes = c.n_planes;
   d.use_limits = c.use_limits; d.n_goals = c.n_goals; d.plane_abs = c.plane_abs;
   d.zero_small = c.zero_small_action; d.obst_dim = c.obst_dim; d.goal_mask = c.goal_estimate_mask;
+  d.ego_mask = c.ego_link_mask;
   d.dt = (T)c.dt; d.eps = (T)c.eps; d.jsign = (T)c.jdot_sign; d.goal_T = (T)c.goal_estimate_T;
   d.base_mass = (T)c.base_mass;
   d.attr_k = (T)c.attr_k; d.attr_alpha = (T)c.attr_alpha; d.attr_mu = (T)c.attr_mu; d.attr_ml = (T)c.attr_ml;
@@ -944,6 +943,7 @@ void common_defaults(mrf_config* c) {
   c->eta_a = 0.9 * (1.0 - 0.5); c->eta_s = 0.5;
   c->plane_abs = 1;
   c->zero_small_action = 1;
+  c->ego_link_mask = 0x3F;
   c->dt = 0.01;
   // library defaults (recalled, overridable): limits and plane finsler
   set_leaf(c->limit_geometry, MRF_FAMILY_POW, MRF_GATE_NONE, 1, -0.1, 0, 0);
@@ -960,6 +960,8 @@ std::string validate(const mrf_config& c) {
   if (c.n_spheres < 0 || c.n_spheres > MRF_MAX_SPHERES) return "n_spheres out of range";
   if (c.horizon < 1) return "horizon must be >= 1";
   if (c.model == MRF_MODEL_PANDA7 && c.n_ego != 0 && c.n_ego != MRF_N_EGO) return "panda n_ego must be 0 or 6";
+  if (c.model == MRF_MODEL_PANDA7 && c.n_ego == MRF_N_EGO && (c.ego_link_mask < 1 || c.ego_link_mask > 0x3F))
+    return "panda ego_link_mask must select at least one of links 3..8 (bits 0..5); use n_ego = 0 for none";
   if (c.model == MRF_MODEL_PLANAR3 && c.n_ego != 0 && c.n_ego != 1) return "planar3 n_ego must be 0 or 1";
   if (c.n_planes < 0 || c.n_planes > 1) return "n_planes must be 0 or 1";
   if (c.model == MRF_MODEL_PANDA7 && (c.n_goals < 0 || c.n_goals > 3)) return "panda n_goals must be 0..3";

@@ -88,10 +88,8 @@ class ParameterizedFabricPlanner:
         collision_links = list(collision_links or [])
         if self._model == "panda":
             # q-independent links are skipped exactly as fabrics skips sparse FKs (FPJ:39,164: `coll_i > 2`)
-            active = sorted({link_number(name) for name in collision_links if link_number(name) > 2})
-            if active and active != [3, 4, 5, 6, 7, 8]:
-                raise NotImplementedError(f"collision links {active}: the kernels carry leaves on links 3..8 (all) or none")
-            n_ego = 6 if active else 0
+            active = sorted({min(link_number(name), 8) for name in collision_links if link_number(name) > 2})
+            n_ego = 6 if active else 0               # any subset of links 3..8: mrf_config.ego_link_mask
             if limits is not None:
                 lim = np.asarray(limits, dtype=float)
                 if lim.shape != (7, 2):
@@ -109,10 +107,11 @@ class ParameterizedFabricPlanner:
             self._check_goal(subs)
         if n_ego == 0:
             number_obstacles = number_dynamic_obstacles = 0      # no collision link -> no obstacle / plane leaves
+        self._ego_links = active if self._model == "panda" else []
         self._components = dict(n_ego=n_ego, n_static=int(number_obstacles), n_dynamic=int(number_dynamic_obstacles),
                                 obst_dim=int(dynamic_obstacle_dimension), n_planes=int(number_plane_constraints) if n_ego else 0,
                                 limits=None if limits is None else np.asarray(limits, dtype=float), n_goals=n_goals)
-        links = [3, 4, 5, 6, 7, 8] if (self._model == "panda" and n_ego) else ([1] if n_ego else [])
+        links = self._ego_links if (self._model == "panda" and n_ego) else ([1] if n_ego else [])
         self.leaves = {}
         for l in links:
             name = "panda_link%d" % l if self._model == "panda" else "base_link"
@@ -156,6 +155,8 @@ class ParameterizedFabricPlanner:
             cfg = _config.panda_config(n_robots=1, horizon=1, n_ego=c["n_ego"], mounts=[self._forward_kinematics.mount],
                                        **self._strings)
             cfg.n_planes = c["n_planes"]
+            if c["n_ego"]:
+                cfg.ego_link_mask = _config.ego_link_mask(self._ego_links)
             cfg.use_limits = 0 if c["limits"] is None else 1
             if c["limits"] is not None:
                 for j in range(7):
@@ -189,7 +190,7 @@ class ParameterizedFabricPlanner:
         keys += ["constraint_%d" % j for j in range(c["n_planes"])]
         keys += ["q", "qdot"]
         if c["n_ego"]:
-            keys += [body % l for l in range(3, 9)] if self._model == "panda" else [body]
+            keys += [body % l for l in self._ego_links] if self._model == "panda" else [body]
         keys += ["radius_obst_%d" % j for j in range(c["n_static"])]
         keys += ["radius_obst_dynamic_%d" % j for j in range(c["n_dynamic"])]
         keys += ["weight_goal_%d" % g for g in range(c["n_goals"])]
@@ -240,15 +241,17 @@ class ParameterizedFabricPlanner:
                     raise KeyError("compute_action: missing argument 'constraint_0'")
                 p[abi.P_CONSTRAINT_0:abi.P_CONSTRAINT_0 + 4] = np.asarray(kw["constraint_0"], dtype=float).reshape(4)
             if c["n_ego"]:
+                # only the links that carry leaves need a body radius (the planner has no parameter for the others)
                 if "radius_body_panda_links" in kw:
                     rb = kw["radius_body_panda_links"]
-                    vals = [float(np.asarray(rb[str(l)]).reshape(-1)[0]) for l in range(3, 9)]
+                    vals = {l: float(np.asarray(rb[str(l)]).reshape(-1)[0]) for l in self._ego_links}
                 else:
                     try:
-                        vals = [float(np.asarray(kw["radius_body_panda_link%d" % l]).reshape(-1)[0]) for l in range(3, 9)]
+                        vals = {l: float(np.asarray(kw["radius_body_panda_link%d" % l]).reshape(-1)[0]) for l in self._ego_links}
                     except KeyError as e:
                         raise KeyError(f"compute_action: missing argument {e.args[0]!r}") from None
-                p[abi.P_RADIUS_BODY:abi.P_RADIUS_BODY + 6] = vals
+                for l, r in vals.items():
+                    p[abi.P_RADIUS_BODY + l - 3] = r
         elif c["n_ego"]:
             if "radius_body_base_link" not in kw:
                 raise KeyError("compute_action: missing argument 'radius_body_base_link'")

@@ -83,6 +83,10 @@ class ForwardFabricsPlanner:
                                    mounts=[p._forward_kinematics.mount for p in self.planners], **p0._strings)
         comp = p0._components
         cfg.n_ego, cfg.n_planes, cfg.n_goals = comp["n_ego"], comp["n_planes"], comp["n_goals"]
+        if any(p._ego_links != p0._ego_links for p in self.planners):
+            raise NotImplementedError("all robots of one rollout share their collision-link set")
+        if comp["n_ego"]:
+            cfg.ego_link_mask = _config.ego_link_mask(p0._ego_links)
         cfg.use_limits = 0 if comp["limits"] is None else 1
         if comp["limits"] is not None:
             for j in range(7):

@@ -377,6 +377,7 @@ void solve_fabric(const mrf_config& cfg, int robot, const Row& row, const std::v
   const double zero3[3] = {0, 0, 0};
   for (int e = 0; e < cfg.n_ego; ++e) {
     int link = cfg.model == MRF_MODEL_PANDA7 ? 3 + e : 1;
+    if (cfg.model == MRF_MODEL_PANDA7 && !((cfg.ego_link_mask >> e) & 1)) continue;  // collision_links subset (EXJ:91-96)
     PointKin K;
     point_kin(C, link, zero3, row.qd, K);
     double r_body = row.prm[MRF_P_RADIUS_BODY + e];

@@ -492,3 +492,58 @@ def test_joint_sincos_multi_revolution_angles(oracle):
     assert relerr(x.cpu().numpy(), wx) < 1e-11
     assert relerr(v.cpu().numpy(), wv) < 1e-11
     assert relerr(a.cpu().numpy(), wa) < 1e-11
+
+
+@pytest.mark.parametrize("mask", [0b000100, 0b010000, 0b101001, 0b001100, 0b111110])
+def test_collision_link_subsets(oracle, mask):
+    """mrf_config.ego_link_mask: collision + plane leaves on a subset of links 3..8 (set_components' collision_links,
+    EXJ:91-96; the Cartesian rollout class defaults to link 7 alone, FPC:20-21; set_planner_panda's own default is link
+    5).  0b001100 = links 5 and 6, the two that share one point; 0b000100 / 0b001000-type masks split that pair.
+    Every kernel family against the oracle: explicit-obstacle action, coupled action, both coupled rollouts
+    (row-per-lane and cooperative), Cartesian rollout, robot-sharded step kernels."""
+    N, H, B = 3, 5, 23
+    cfg = config.panda_config(n_robots=N, horizon=H)
+    cfg.ego_link_mask = mask
+    cfg.goal_estimate_mask = 0b110
+    batch = scenarios.panda_batch(cfg, B, seed=mask, x_min=0.1)
+    rng = np.random.default_rng(mask)
+    batch["params"][abi.P_RADIUS_BODY:abi.P_RADIUS_BODY + 6] = rng.uniform(0.05, 0.09, (6, B * N))   # distinct radii per link
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
+    want_qdd, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    full = cfg.copy()
+    full.ego_link_mask = 0x3F
+    _, act_full = oracle.compute_action(full, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    assert relerr(want_act, act_full) > 1e-6          # the mask matters on this batch
+    wc_avg, _, wc_qd = oracle.rollout_cartesian(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad, traj=True)
+    for kernel in (1, 2):
+        c = cfg.copy()
+        c.kernel_select = kernel
+        h = FabricHandle(c, 0)
+        q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+        avg, tq, tqd = h.rollout(q, qd, prm, want_traj=True)
+        assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL and relerr(avg.cpu().numpy(), want_avg) < F64_RTOL, kernel
+        act_c = h.compute_action_coupled(q, qd, prm, use_accel=True)
+        assert relerr(act_c.cpu().numpy(), want_act) < F64_RTOL, kernel
+    act, qdd = h.compute_action(q, qd, prm, h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad), want_qddot=True)
+    assert relerr(act.cpu().numpy(), want_act) < F64_RTOL and relerr(qdd.cpu().numpy(), want_qdd) < F64_RTOL
+    cavg, _, ctqd = h.rollout_cartesian(q, qd, prm, h.tensor(ox), h.tensor(ov), h.tensor(oa), h.tensor(orad), want_traj=True)
+    assert relerr(ctqd.cpu().numpy(), wc_qd) < F64_RTOL and relerr(cavg.cpu().numpy(), wc_avg) < F64_RTOL
+    from multi_robot_fabrics_amd.sharded import ShardedRollout
+    for transport in ("rccl", "peer"):
+        sr = ShardedRollout(cfg, 0, 1, device_index=0, transport=transport, max_scenarios=B)
+        qq, qqd = q.clone(), qd.clone()
+        savg = sr.rollout(qq, qqd, prm)
+        sr.backend.h.comm_status()
+        assert relerr(savg.cpu().numpy(), want_avg) < F64_RTOL and relerr(qqd.cpu().numpy(), want_qd[-1]) < F64_RTOL, transport
+
+
+def test_validate_rejects_an_empty_link_mask():
+    from multi_robot_fabrics_amd.runtime import MrfError
+    cfg = config.panda_config(n_robots=2, horizon=2)
+    cfg.ego_link_mask = 0
+    with pytest.raises(MrfError):
+        FabricHandle(cfg, 0)
+    cfg.n_ego = 0               # "grasp" planner: no collision links at all, the mask is not looked at
+    FabricHandle(cfg, 0)

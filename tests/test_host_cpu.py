@@ -185,8 +185,14 @@ def test_planner_argument_marshalling():
     del kw["xdot_obsts_dynamic"]
     with pytest.raises(KeyError):
         planner.obstacle_arrays(kw)
-    with pytest.raises(NotImplementedError):
-        planner.set_components(collision_links=["panda_link5"], goal=None, number_obstacles=1)
+    # a subset of the collision links (the reference's set_planner_panda default is link 5 alone, EXJ:64) is a mask
+    planner.set_components(collision_links=["panda_link1", "panda_link5", "panda_hand"], goal=None, number_obstacles=1,
+                           number_plane_constraints=1)
+    assert planner._ego_links == [5, 8] and config.ego_link_mask(planner._ego_links) == 0b100100
+    assert sorted(k for k in planner.leaves if "obst" in k) == ["panda_link5_obst_0_leaf", "panda_link8_obst_0_leaf"]
+    assert "radius_body_panda_link5" in planner.input_keys() and "radius_body_panda_link3" not in planner.input_keys()
+    with pytest.raises(KeyError):
+        planner.set_components(collision_links=["panda_link9"], goal=None)
 
 
 def test_urdf_constants_are_checked():

@@ -218,3 +218,26 @@ def test_goal_estimate_mask(oracle):
     cfg.goal_estimate_mask = 0
     avg_e, _, tqd_e = oracle.rollout(cfg, b["q"], b["qdot"], p2, traj=True)
     assert rel(tqd_m, tqd_e) < 1e-13
+
+
+@pytest.mark.parametrize("links", [(7,), (5,), (3, 6, 8)])
+def test_collision_link_subsets_match_autodiff(oracle, links):
+    """ego_link_mask in the oracle against the autodiff oracle built with the same collision_links (EXJ:91-96)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import autodiff_oracle as ao
+    g = np.load(os.path.join(GOLD, "panda_actions.npz"))
+    i = 0                                              # a "dynamic" case with 4 obstacle spheres
+    P = ao.Planner(mount=g["mount"][i], n_dynamic=4, collision_links=links)
+    rb = {l: 0.05 + 0.01 * l for l in range(3, 9)}
+    out = P.solve(g["q"][i], g["qd"][i], x_obsts_dynamic=g["ox"][i], xdot_obsts_dynamic=g["ov"][i],
+                  xddot_obsts_dynamic=g["oa"][i], radius_obsts_dynamic=g["orad"][i], x_goal_0=g["g0"][i],
+                  weight_goal_0=2.0, angle_goal_1=R1, x_goal_1=[0.107, 0.0, 0.0], weight_goal_1=20.0,
+                  x_goal_2=[math.pi / 4], weight_goal_2=1.0, constraint_0=[0.0, 0.0, 1.0, -0.65], radius_body=rb,
+                  return_parts=True)
+    cfg = config.panda_config(n_robots=1, horizon=1, mounts=[g["mount"][i]])
+    cfg.ego_link_mask = config.ego_link_mask(links)
+    prm = params_row(g["g0"][i], [rb[l] for l in range(3, 9)])
+    _, act = oracle.compute_action(cfg, g["q"][i][:, None], g["qd"][i][:, None], prm[:, None], g["ox"][i][:, :, None],
+                                   g["ov"][i][:, :, None], g["oa"][i][:, :, None], g["orad"][i][:, None])
+    assert rel(act[:, 0], out["action"]) < 1e-10
