@@ -295,6 +295,64 @@ int mrf_deadlock_step(mrf_handle* h, int64_t n_scenarios, const mrf_deadlock_con
 int mrf_apply_action(mrf_handle* h, int64_t rows, void* q_io, void* qdot_io, void* action_io, const double* vel_limit,
                      double stop_margin, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Pick-and-place sequencing on the device: StateMachine.get_state_machine_panda of
+ * multi_robot_fabrics/others_planner/state_machine.py:133-214 and get_gripper_action_panda (:66-86) for every row,
+ * as the driver runs them per robot before the fabric calls (example_pandas_Jointspace.py:304-316, 448).
+ * Per-row state:  int32 sm_state[MRF_SM_NSTATE][rows],  scalar sm_goal[MRF_SM_NGOAL][rows].
+ * States (SM:150-199): 0 go home / open, 1 above the block, 2 down to it, 3 grip (0.3 s), 12 lift, 4 carry home,
+ * 5 release, 10 all blocks done.  The Kinova variant of the reference (a second robot type) is not built. */
+#define MRF_SM_STATE 0    /* the value get_state_machine_panda returns; this row is the sm_state input of mrf_deadlock_step */
+#define MRF_SM_PICKED 1   /* nr_blocks_panda_success */
+#define MRF_SM_FAILED 2   /* nr_blocks_panda_failed  */
+#define MRF_SM_T_GRIP 3   /* time_gripping_panda     */
+#define MRF_SM_GRIPPER 4  /* 0 "open", 1 "close"     */
+#define MRF_SM_STOP 5     /* stop_time_panda         */
+#define MRF_SM_NSTATE 6
+#define MRF_SM_GOAL 0       /* [3] self.goal            */
+#define MRF_SM_GOAL_ABOVE 3 /* [3] self.goal_above_block */
+#define MRF_SM_WEIGHT 6     /* self.weight_goal         */
+#define MRF_SM_NGOAL 7
+typedef struct mrf_state_machine_config { /* literals of state_machine.py:133-214 and :66-86 */
+  double reach_home, reach_pregrasp, reach_block, reach_lift, reach_drop; /* 0.05 0.013 0.013 0.04 0.15 */
+  double pregrasp_height, lift_height;    /* 0.1, 0.15 */
+  double grip_steps;                      /* 0.3/0.01: the grip is held while time_gripping <= this */
+  double open_tol, dropped_below_z;       /* 0.005, 0.6 */
+  double weight_high, weight_low;         /* 2, 0 */
+  double gripper_open[2];                 /* [0.04, 0.04] */
+  double v_close, v_open;                 /* -0.05, 0.4 */
+  int32_t nr_blocks;                      /* blocks per robot (n_cubes / nr_robots, EXJ:255) */
+  int32_t model;                          /* 0: block and gripper observations are inputs (as from a simulator);
+                                             1: minimal built-in model for simulator-free episodes: the block of a row is
+                                             blocks[min(picked, nr_blocks-1)], carried with the hand while the gripper is
+                                             closed in states 12/4, and the finger joints integrate their own velocity
+                                             command (q += dt * action, clipped to [0, gripper_open]) */
+} mrf_state_machine_config;
+void mrf_default_state_machine_config(mrf_state_machine_config* c, int32_t nr_blocks);
+int64_t mrf_state_machine_config_sizeof(void);
+/* initial object state (SM:9-38): state 1, goal = start_goal [3][rows], weight 2, gripper open */
+int mrf_state_machine_init(mrf_handle* h, int64_t rows, const void* start_goal, int32_t* sm_state, void* sm_goal, void* stream);
+/* One update of every row.  x_ee [3][rows] (mrf_control_prepare), start_goal [3][rows],
+ * blocks [n_block_arrays][3][rows]: model 0 reads blocks[0] as this step's goal_block (already lifted by 0.1 as the
+ * driver does, EXJ:303); model 1 indexes it by the picked count.  q_gripper_io [2][rows] finger joints (model 1 advances
+ * them).  Writes x_goal_0 / weight_goal_0 of params_work for the rows whose robot bit is NOT in skip_robot_mask (the
+ * RF-CV estimate of mrf_control_prepare overrides the state machine's goal there, EXJ:346-348), and the gripper
+ * velocity command gripper_action_out [2][rows] (may be NULL). */
+int mrf_state_machine_step(mrf_handle* h, int64_t rows, const mrf_state_machine_config* sm, const void* x_ee,
+                           const void* start_goal, const void* blocks, int32_t n_block_arrays, void* q_gripper_io,
+                           int32_t* sm_state, void* sm_goal, void* params_work, int32_t skip_robot_mask,
+                           void* gripper_action_out, void* stream);
+/* Attaches pick-and-place buffers to an action handle: every control step of mrf_episode_run on that handle then runs
+ * mrf_state_machine_step between mrf_control_prepare and the rollout, feeds sm_state row MRF_SM_STATE to the
+ * deadlock logic (the `sm_state` argument of mrf_episode_run is ignored), and selects the action per row as the
+ * driver does (EXJ:414-445): states 3 and 5 stand still (zero action); state 2 takes the action of h_grasp -- the
+ * "grasp" planner without collision links (EXJ:160-166; a handle created with n_ego = 0 and the same mounts), written
+ * to action_grasp_work [dof][rows]; NULL h_grasp keeps the full planner in state 2.  All arrays are caller-owned and
+ * must outlive the episodes; sm == NULL detaches. */
+int mrf_episode_set_pick_place(mrf_handle* h_action, const mrf_state_machine_config* sm, const void* start_goal,
+                               const void* blocks, int32_t n_block_arrays, void* q_gripper_io, int32_t* sm_state,
+                               void* sm_goal, void* gripper_action_out, mrf_handle* h_grasp, void* action_grasp_work);
+
 /* n_steps control steps on the device.  h_rollout may be NULL (no Rollout Fabrics, no deadlock logic: plain MRDF);
  * dl may be NULL (rollouts monitored, no deadlock logic).  Work buffers are caller-owned:
  *   params_work [MRF_NPARAM][rows]  x_ee_work [3][rows]  avg_work [rows]  action_out [dof][rows] (last step's action)

@@ -80,6 +80,8 @@ EXPORTS = [
     "mrf_fk_spheres", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
+    "mrf_default_state_machine_config", "mrf_state_machine_config_sizeof", "mrf_state_machine_init", "mrf_state_machine_step",
+    "mrf_episode_set_pick_place",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
     "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_destroy",
 ]
@@ -98,6 +100,21 @@ class DeadlockConfig(C.Structure):
                 ("follower_offset", C.c_double), ("min_goal_norm", C.c_double), ("z_floor", C.c_double),
                 ("time_wait", C.c_int32), ("min_time_step", C.c_int32), ("grasp_state", C.c_int32),
                 ("grasp_timeout", C.c_int32)]
+
+# rows of the pick-and-place state (include/mrf.h MRF_SM_*)
+SM_STATE, SM_PICKED, SM_FAILED, SM_T_GRIP, SM_GRIPPER, SM_STOP, SM_NSTATE = range(7)
+SM_GOAL, SM_GOAL_ABOVE, SM_WEIGHT, SM_NGOAL = 0, 3, 6, 7
+
+
+class StateMachineConfig(C.Structure):
+    """ctypes mirror of mrf_state_machine_config (literals of state_machine.py:133-214 and :66-86)."""
+    _fields_ = [("reach_home", C.c_double), ("reach_pregrasp", C.c_double), ("reach_block", C.c_double),
+                ("reach_lift", C.c_double), ("reach_drop", C.c_double), ("pregrasp_height", C.c_double),
+                ("lift_height", C.c_double), ("grip_steps", C.c_double), ("open_tol", C.c_double),
+                ("dropped_below_z", C.c_double), ("weight_high", C.c_double), ("weight_low", C.c_double),
+                ("gripper_open", C.c_double * 2), ("v_close", C.c_double), ("v_open", C.c_double),
+                ("nr_blocks", C.c_int32), ("model", C.c_int32)]
+
 
 _lib = None
 
@@ -169,6 +186,17 @@ def load_library(path=None):
     lib.mrf_episode_run.argtypes = [vp, vp, i64, i32, dlp, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, vp, vp,
                                     vp, vp, vp, vp, vp, i32, vp]
     lib.mrf_episode_run.restype = C.c_int
+    smp = C.POINTER(StateMachineConfig)
+    lib.mrf_default_state_machine_config.argtypes = [smp, i32]
+    lib.mrf_default_state_machine_config.restype = None
+    lib.mrf_state_machine_config_sizeof.argtypes = []
+    lib.mrf_state_machine_config_sizeof.restype = C.c_int64
+    lib.mrf_state_machine_init.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.mrf_state_machine_init.restype = C.c_int
+    lib.mrf_state_machine_step.argtypes = [vp, i64, smp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.mrf_state_machine_step.restype = C.c_int
+    lib.mrf_episode_set_pick_place.argtypes = [vp, smp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.mrf_episode_set_pick_place.restype = C.c_int
     lib.mrf_comm_unique_id.argtypes = [vp]
     lib.mrf_comm_unique_id.restype = C.c_int
     lib.mrf_comm_init.argtypes = [vp, i32, i32, vp]
@@ -193,6 +221,8 @@ def load_library(path=None):
         raise MrfLibraryError(f"mrf_config size mismatch: C {lib.mrf_config_sizeof()} != ctypes {C.sizeof(Config)}")
     if lib.mrf_deadlock_config_sizeof() != C.sizeof(DeadlockConfig):
         raise MrfLibraryError("mrf_deadlock_config size mismatch")
+    if lib.mrf_state_machine_config_sizeof() != C.sizeof(StateMachineConfig):
+        raise MrfLibraryError("mrf_state_machine_config size mismatch")
     if path is None:
         _lib = lib
     return lib

@@ -167,6 +167,169 @@ __global__ __launch_bounds__(256) void k_deadlock_init(int64_t n_scen, int32_t* 
   for (int c = 0; c < 3; ++c) dl_goal[c * n_scen + b] = T(0);
 }
 
+// ---------------------------------------------------------------------------- pick-and-place state machine
+template <typename T>
+struct SmCfg {
+  T reach_home, reach_pregrasp, reach_block, reach_lift, reach_drop, pregrasp_height, lift_height, grip_steps, open_tol,
+      dropped_below_z, weight_high, weight_low, open0, open1, v_close, v_open, dt;
+  int nr_blocks, model;
+};
+
+// One thread per row; statement order follows get_state_machine_panda (SM:133-214) and get_gripper_action_panda (:66-86).
+template <typename T>
+__global__ __launch_bounds__(64) void k_state_machine(const DevCfg<T>* __restrict__ cfgp, int64_t rows, SmCfg<T> C,
+                                                       const T* __restrict__ x_ee, const T* __restrict__ start,
+                                                       const T* __restrict__ blocks, int n_block_arrays,
+                                                       T* __restrict__ q_grip, int32_t* __restrict__ st,
+                                                       T* __restrict__ sg, T* __restrict__ prm, int skip_mask,
+                                                       T* __restrict__ grip_act) {
+#pragma clang fp contract(off)  // plain mul/add as numpy evaluates them
+  const DevCfg<T>& cfg = *cfgp;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int state = st[MRF_SM_STATE * rows + r], picked = st[MRF_SM_PICKED * rows + r], failed = st[MRF_SM_FAILED * rows + r];
+  int t_grip = st[MRF_SM_T_GRIP * rows + r], closed = st[MRF_SM_GRIPPER * rows + r], stop = st[MRF_SM_STOP * rows + r];
+  T goal[3], above_blk[3], x[3], s0[3], g[2];
+  for (int c = 0; c < 3; ++c) {
+    goal[c] = sg[(MRF_SM_GOAL + c) * rows + r];
+    above_blk[c] = sg[(MRF_SM_GOAL_ABOVE + c) * rows + r];
+    x[c] = x_ee[c * rows + r];
+    s0[c] = start[c * rows + r];
+  }
+  T weight = sg[MRF_SM_WEIGHT * rows + r];
+  g[0] = q_grip[r];
+  g[1] = q_grip[rows + r];
+  // goal_block of this step: an observation (model 0) or the minimal block model (model 1)
+  int bi = 0;
+  if (C.model == 1) bi = picked < C.nr_blocks - 1 ? picked : C.nr_blocks - 1;
+  if (bi >= n_block_arrays) bi = n_block_arrays - 1;
+  T block[3];
+  for (int c = 0; c < 3; ++c) block[c] = blocks[((int64_t)bi * 3 + c) * rows + r];
+  if (C.model == 1 && closed && (state == 12 || state == 4))
+    for (int c = 0; c < 3; ++c) block[c] = x[c];  // carried: the grasp target travels with the hand
+  T pre[3] = {block[0], block[1], block[2] + C.pregrasp_height};
+  auto norm3 = [](T a, T b, T c) { return m_sqrt(a * a + b * b + c * c); };
+  auto norm2 = [](T a, T b) { return m_sqrt(a * a + b * b); };
+  const T d_home = norm3(x[0] - s0[0], x[1] - s0[1], x[2] - s0[2]);
+  const T d_pre = norm2(x[0] - pre[0], x[1] - pre[1]);  // get_distance_ee_goal: horizontal only (SM:51-54)
+  const T d_block = norm3(x[0] - block[0], x[1] - block[1], x[2] - block[2]);
+  const T d_open = norm2(g[0] - C.open0, g[1] - C.open1);
+
+  if (picked > C.nr_blocks - 1) {
+    state = 10;
+  } else if (block[2] < C.dropped_below_z) {  // "the block has been dropped!"
+    picked += 1;
+    failed += 1;
+    state = 0;
+  }
+  if (state == 0) {
+    for (int c = 0; c < 3; ++c) goal[c] = s0[c];
+    closed = 0;
+    if (d_home < C.reach_home) state = 1;
+  } else if (state == 1) {
+    for (int c = 0; c < 3; ++c) goal[c] = pre[c];
+    if (d_pre < C.reach_pregrasp) state = 2;
+  } else if (state == 2) {
+    for (int c = 0; c < 3; ++c) goal[c] = block[c];
+    if (d_block < C.reach_block) {
+      closed = 1;
+      weight = C.weight_low;
+      state = 3;
+    }
+  } else if (state == 3) {
+    for (int c = 0; c < 3; ++c) {
+      goal[c] = block[c];
+      above_blk[c] = block[c];
+    }
+    above_blk[2] += C.lift_height;
+    t_grip += 1;
+    if ((T)t_grip > C.grip_steps) {
+      t_grip = 0;
+      for (int c = 0; c < 3; ++c) goal[c] = s0[c];
+      weight = C.weight_high;
+      state = 12;
+    }
+  } else if (state == 12) {
+    for (int c = 0; c < 3; ++c) goal[c] = above_blk[c];
+    if (norm2(x[0] - goal[0], x[1] - goal[1]) < C.reach_lift) state = 4;
+  } else if (state == 4) {
+    for (int c = 0; c < 3; ++c) goal[c] = s0[c];
+    if (d_home < C.reach_drop) {
+      state = 5;
+      closed = 0;
+    }
+  } else if (state == 5) {
+    if (d_open < C.open_tol) {
+      state = 0;
+      picked += 1;
+      for (int c = 0; c < 3; ++c) goal[c] = s0[c];
+    }
+  } else if (state == 10) {
+    stop = 1;
+  }
+  // get_gripper_action_panda (SM:66-86), evaluated on the updated gripper status as the driver does (EXJ:448)
+  T act[2] = {T(0), T(0)};
+  if (closed) {
+    act[0] = act[1] = C.v_close;
+  } else if (d_open > C.open_tol) {
+    act[0] = g[0] > C.open0 ? -C.v_open : C.v_open;
+    act[1] = g[1] > C.open1 ? -C.v_open : C.v_open;
+  }
+  if (grip_act) {
+    grip_act[r] = act[0];
+    grip_act[rows + r] = act[1];
+  }
+  if (C.model == 1) {  // finger joints follow their velocity command between the mechanical stops
+    q_grip[r] = m_min(m_max(g[0] + C.dt * act[0], T(0)), C.open0);
+    q_grip[rows + r] = m_min(m_max(g[1] + C.dt * act[1], T(0)), C.open1);
+  }
+  st[MRF_SM_STATE * rows + r] = state;
+  st[MRF_SM_PICKED * rows + r] = picked;
+  st[MRF_SM_FAILED * rows + r] = failed;
+  st[MRF_SM_T_GRIP * rows + r] = t_grip;
+  st[MRF_SM_GRIPPER * rows + r] = closed;
+  st[MRF_SM_STOP * rows + r] = stop;
+  for (int c = 0; c < 3; ++c) {
+    sg[(MRF_SM_GOAL + c) * rows + r] = goal[c];
+    sg[(MRF_SM_GOAL_ABOVE + c) * rows + r] = above_blk[c];
+  }
+  sg[MRF_SM_WEIGHT * rows + r] = weight;
+  const int robot = (int)(r % cfg.n_robots);
+  if (prm && !((skip_mask >> robot) & 1)) {  // EXJ:313-316 -> :423-424
+    for (int c = 0; c < 3; ++c) prm[(MRF_P_X_GOAL_0 + c) * rows + r] = goal[c];
+    prm[MRF_P_WEIGHT_GOAL_0 * rows + r] = weight;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_state_machine_init(int64_t rows, const T* __restrict__ start,
+                                                             int32_t* __restrict__ st, T* __restrict__ sg) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  st[MRF_SM_STATE * rows + r] = 1;  // SM:14
+  for (int k = 1; k < MRF_SM_NSTATE; ++k) st[k * rows + r] = 0;
+  for (int c = 0; c < 3; ++c) {
+    sg[(MRF_SM_GOAL + c) * rows + r] = start[c * rows + r];
+    sg[(MRF_SM_GOAL_ABOVE + c) * rows + r] = T(0);
+  }
+  sg[MRF_SM_WEIGHT * rows + r] = T(2);  // SM:11
+}
+
+// per-row action selection of the driver (EXJ:414-445): gripping / releasing rows stand still, descending rows take the
+// grasp planner's action
+template <typename T>
+__global__ __launch_bounds__(256) void k_select_action(int64_t rows, int dof, const int32_t* __restrict__ sm_state,
+                                                        const T* __restrict__ act_grasp, T* __restrict__ act) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int s = sm_state[r];
+  if (s == 3 || s == 5) {
+    for (int j = 0; j < dof; ++j) act[j * rows + r] = T(0);
+  } else if (s == 2 && act_grasp) {
+    for (int j = 0; j < dof; ++j) act[j * rows + r] = act_grasp[j * rows + r];
+  }
+}
+
 template <typename T>
 struct VelLimits {
   T v[MRF_DOF_MAX];
@@ -281,6 +444,81 @@ int mrf_deadlock_step(mrf_handle* h, int64_t n_scen, const mrf_deadlock_config* 
   });
 }
 
+int64_t mrf_state_machine_config_sizeof(void) { return (int64_t)sizeof(mrf_state_machine_config); }
+
+void mrf_default_state_machine_config(mrf_state_machine_config* c, int32_t nr_blocks) {
+  std::memset(c, 0, sizeof(*c));
+  c->reach_home = 0.05; c->reach_pregrasp = 0.013; c->reach_block = 0.013; c->reach_lift = 0.04; c->reach_drop = 0.15;
+  c->pregrasp_height = 0.1; c->lift_height = 0.15;
+  c->grip_steps = 0.3 / 0.01;  // SM:171, evaluated in double as Python does (29.999999999999996)
+  c->open_tol = 0.005; c->dropped_below_z = 0.6;
+  c->weight_high = 2.0; c->weight_low = 0.0;
+  c->gripper_open[0] = c->gripper_open[1] = 0.04;
+  c->v_close = -0.05; c->v_open = 0.4;
+  c->nr_blocks = nr_blocks;
+  c->model = 0;
+}
+
+int mrf_state_machine_init(mrf_handle* h, int64_t rows, const void* start_goal, int32_t* sm_state, void* sm_goal, void* stream) {
+  MRF_CHECK_READY(h);
+  if (rows == 0) return MRF_OK;
+  if (rows < 0 || !start_goal || !sm_state || !sm_goal) return fail(h, MRF_E_ARG, "null/negative argument");
+  dim3 block(256), grid((unsigned)((rows + 255) / 256));
+  return dispatch_scalar(h, [&](auto t) {
+    using T = decltype(t);
+    return launch(h, mrf::k_state_machine_init<T>, grid, block, (hipStream_t)stream, rows, (const T*)start_goal, sm_state, (T*)sm_goal);
+  });
+}
+
+int mrf_state_machine_step(mrf_handle* h, int64_t rows, const mrf_state_machine_config* sm, const void* x_ee,
+                           const void* start_goal, const void* blocks, int32_t n_block_arrays, void* q_gripper_io,
+                           int32_t* sm_state, void* sm_goal, void* params_work, int32_t skip_robot_mask,
+                           void* gripper_action_out, void* stream) {
+  MRF_CHECK_READY(h);
+  if (rows == 0) return MRF_OK;
+  if (rows < 0 || !sm || !x_ee || !start_goal || !blocks || n_block_arrays < 1 || !q_gripper_io || !sm_state || !sm_goal)
+    return fail(h, MRF_E_ARG, "null/negative argument");
+  if (sm->nr_blocks < 1 || (sm->model != 0 && sm->model != 1)) return fail(h, MRF_E_CONFIG, "nr_blocks >= 1 and model in {0,1}");
+  dim3 block(64), grid((unsigned)((rows + 63) / 64));
+  return dispatch_scalar(h, [&](auto t) {
+    using T = decltype(t);
+    mrf::SmCfg<T> C;
+    C.reach_home = (T)sm->reach_home; C.reach_pregrasp = (T)sm->reach_pregrasp; C.reach_block = (T)sm->reach_block;
+    C.reach_lift = (T)sm->reach_lift; C.reach_drop = (T)sm->reach_drop; C.pregrasp_height = (T)sm->pregrasp_height;
+    C.lift_height = (T)sm->lift_height; C.grip_steps = (T)sm->grip_steps; C.open_tol = (T)sm->open_tol;
+    C.dropped_below_z = (T)sm->dropped_below_z; C.weight_high = (T)sm->weight_high; C.weight_low = (T)sm->weight_low;
+    C.open0 = (T)sm->gripper_open[0]; C.open1 = (T)sm->gripper_open[1]; C.v_close = (T)sm->v_close; C.v_open = (T)sm->v_open;
+    C.dt = (T)h->cfg.dt; C.nr_blocks = sm->nr_blocks; C.model = sm->model;
+    return launch(h, mrf::k_state_machine<T>, grid, block, (hipStream_t)stream, (const mrf::DevCfg<T>*)h->dcfg, rows, C,
+                  (const T*)x_ee, (const T*)start_goal, (const T*)blocks, (int)n_block_arrays, (T*)q_gripper_io, sm_state,
+                  (T*)sm_goal, (T*)params_work, (int)skip_robot_mask, (T*)gripper_action_out);
+  });
+}
+
+int mrf_episode_set_pick_place(mrf_handle* h, const mrf_state_machine_config* sm, const void* start_goal,
+                               const void* blocks, int32_t n_block_arrays, void* q_gripper_io, int32_t* sm_state,
+                               void* sm_goal, void* gripper_action_out, mrf_handle* h_grasp, void* action_grasp_work) {
+  MRF_CHECK_READY(h);
+  if (!sm) {
+    h->pp = mrf_handle::PickPlace();
+    return MRF_OK;
+  }
+  if (!start_goal || !blocks || n_block_arrays < 1 || !q_gripper_io || !sm_state || !sm_goal)
+    return fail(h, MRF_E_ARG, "null argument");
+  if (sm->nr_blocks < 1 || (sm->model != 0 && sm->model != 1)) return fail(h, MRF_E_CONFIG, "nr_blocks >= 1 and model in {0,1}");
+  h->pp.on = true;
+  h->pp.sm = *sm;
+  h->pp.start_goal = start_goal; h->pp.blocks = blocks; h->pp.n_block_arrays = n_block_arrays;
+  if (h_grasp) {
+    if (!h_grasp->dcfg || !action_grasp_work) return fail(h, MRF_E_ARG, "grasp handle without device state / work buffer");
+    if (h_grasp->cfg.n_robots != h->cfg.n_robots || h_grasp->cfg.scalar != h->cfg.scalar || h_grasp->device != h->device)
+      return fail(h, MRF_E_CONFIG, "grasp and action handles must agree in n_robots, scalar type and device");
+  }
+  h->pp.q_gripper = q_gripper_io; h->pp.sm_state = sm_state; h->pp.sm_goal = sm_goal; h->pp.gripper_action = gripper_action_out;
+  h->pp.h_grasp = h_grasp; h->pp.grasp_serial = h_grasp ? h_grasp->serial : 0; h->pp.action_grasp = h_grasp ? action_grasp_work : nullptr;
+  return MRF_OK;
+}
+
 int mrf_apply_action(mrf_handle* h, int64_t rows, void* q_io, void* qdot_io, void* action_io, const double* vel_limit,
                      double stop_margin, void* stream) {
   MRF_CHECK_READY(h);
@@ -304,12 +542,38 @@ static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mr
                         void* act, void* st) {
   const int64_t rows = n_scen * ha->cfg.n_robots;
   int rc;
+  const mrf_handle::PickPlace& pp = ha->pp;
+  if (hr || pp.on) {  // hand FK (+ RF-CV estimate), then the state machine's goals for the rows the estimate left alone
+    mrf_handle* hp = hr ? hr : ha;
+    const int est = hr ? apply_estimate : 0;
+    if ((rc = mrf_control_prepare(hp, n_scen, q, qd, prm_nom, prm_work, est, x_ee, st))) return rc;
+    if (pp.on) {
+      if ((rc = mrf_state_machine_step(ha, rows, &pp.sm, x_ee, pp.start_goal, pp.blocks, pp.n_block_arrays, pp.q_gripper,
+                                       pp.sm_state, pp.sm_goal, prm_work, est ? hp->cfg.goal_estimate_mask : 0,
+                                       pp.gripper_action, st)))
+        return rc;
+      sm = pp.sm_state;  // row MRF_SM_STATE (the first `rows` entries)
+    }
+  }
   if (hr) {
-    if ((rc = mrf_control_prepare(hr, n_scen, q, qd, prm_nom, prm_work, apply_estimate, x_ee, st))) return rc;
     if ((rc = mrf_rollout(hr, n_scen, q, qd, prm_work, avg, nullptr, nullptr, st))) return rc;
     if (dl && (rc = mrf_deadlock_step(hr, n_scen, dl, -1, x_ee, avg, sm, prm_work, dl_state, dl_goal, st))) return rc;
   }
-  if ((rc = mrf_compute_action_coupled(ha, n_scen, q, qd, hr ? prm_work : prm_nom, 0, nullptr, act, st))) return rc;
+  if ((rc = mrf_compute_action_coupled(ha, n_scen, q, qd, (hr || pp.on) ? prm_work : prm_nom, 0, nullptr, act, st))) return rc;
+  if (pp.on) {
+    if (pp.h_grasp && (rc = mrf_compute_action(pp.h_grasp, rows, q, qd, prm_work, 0, 0, nullptr, nullptr, nullptr, nullptr,
+                                              nullptr, pp.action_grasp, st))) {
+      if (ha->err.empty()) ha->err = pp.h_grasp->err;
+      return rc;
+    }
+    dim3 block(256), grid((unsigned)((rows + 255) / 256));
+    rc = dispatch_scalar(ha, [&](auto t) {
+      using T = decltype(t);
+      return launch(ha, mrf::k_select_action<T>, grid, block, (hipStream_t)st, rows, 7, (const int32_t*)pp.sm_state,
+                    (const T*)pp.action_grasp, (T*)act);
+    });
+    if (rc) return rc;
+  }
   return mrf_apply_action(ha, rows, q, qd, act, vel_limit, stop_margin, st);
 }
 
@@ -326,7 +590,8 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
   if (n_scen == 0 || n_steps == 0) return MRF_OK;
   if (n_scen < 0 || n_steps < 0 || !vel_limit || !q_io || !qdot_io || !params_nominal || !action_out)
     return fail(ha, MRF_E_ARG, "null/negative argument");
-  if (hr && (!params_work || !x_ee_work || !avg_work)) return fail(ha, MRF_E_ARG, "work buffers missing");
+  if ((hr || ha->pp.on) && (!params_work || !x_ee_work)) return fail(ha, MRF_E_ARG, "work buffers missing");
+  if (hr && !avg_work) return fail(ha, MRF_E_ARG, "work buffers missing");
   if (hr && dl && (!dl_state || !dl_goal)) return fail(ha, MRF_E_ARG, "deadlock state missing");
   auto one = [&](void* st) {
     int rc = control_step(hr, ha, n_scen, dl, apply_estimate, vel_limit, stop_margin, q_io, qdot_io, params_nominal,
@@ -359,6 +624,7 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
   const uint64_t ident[] = {ha->serial, hr ? hr->serial : 0, (uint64_t)(uintptr_t)ha->dcfg,
                             (uint64_t)(uintptr_t)(hr ? hr->dcfg : nullptr)};
   key.append((const char*)ident, sizeof(ident));
+  key.append((const char*)&ha->pp, sizeof(ha->pp));  // attached pick-and-place buffers and constants
   key.append((const char*)&dlc, sizeof(dlc));
   key.append((const char*)vel_limit, sizeof(double) * MRF_DOF_MAX);
   key.append((const char*)&stop_margin, sizeof(stop_margin));

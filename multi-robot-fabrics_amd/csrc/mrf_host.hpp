@@ -20,6 +20,21 @@ struct mrf_handle {
   void* graph_exec = nullptr;
   std::string graph_key;
   void* own_stream = nullptr;
+  // pick-and-place buffers attached by mrf_episode_set_pick_place (mrf_control.hip); all caller-owned
+  struct PickPlace {
+    bool on = false;
+    mrf_state_machine_config sm;
+    const void* start_goal = nullptr;
+    const void* blocks = nullptr;
+    int32_t n_block_arrays = 0;
+    void* q_gripper = nullptr;
+    int32_t* sm_state = nullptr;
+    void* sm_goal = nullptr;
+    void* gripper_action = nullptr;
+    mrf_handle* h_grasp = nullptr;
+    uint64_t grasp_serial = 0;
+    void* action_grasp = nullptr;
+  } pp;
   void* comm = nullptr;   // robot-sharded rollout state (mrf_comm.hip): communicator / mapped peer buffers / work buffers
 };
 

@@ -313,6 +313,37 @@ class FabricHandle:
                                         self._arg(dl_goal, (3, n_scen), "dl_goal"), self._stream(stream))
         self._check(rc)
 
+    # ------------------------------------------------------------------ pick-and-place state machine (SM:133-214)
+    def state_machine_config(self, nr_blocks, model=0):
+        c = abi.StateMachineConfig()
+        self.lib.mrf_default_state_machine_config(C.byref(c), int(nr_blocks))
+        c.model = int(model)
+        return c
+
+    def state_machine_state(self, start_goal, stream=None):
+        """Fresh per-row state for start goals [3, rows]: (int32 [SM_NSTATE, rows], goal [SM_NGOAL, rows])."""
+        rows = start_goal.shape[1]
+        st = torch.empty((abi.SM_NSTATE, rows), dtype=torch.int32, device=self.device)
+        sg = torch.empty((abi.SM_NGOAL, rows), dtype=self.dtype, device=self.device)
+        self._check(self.lib.mrf_state_machine_init(self._h, rows, self._arg(start_goal, (3, rows), "start_goal"),
+                                                    C.c_void_p(st.data_ptr()), self._arg(sg), self._stream(stream)))
+        return st, sg
+
+    def state_machine_step(self, sm_cfg, x_ee, start_goal, blocks, q_gripper_io, sm_state, sm_goal, params_work=None,
+                           skip_robot_mask=0, stream=None):
+        """get_state_machine_panda + get_gripper_action_panda for every row -> gripper velocity command [2, rows]."""
+        rows = x_ee.shape[1]
+        nb = blocks.shape[0]
+        act = torch.empty((2, rows), dtype=self.dtype, device=self.device)
+        rc = self.lib.mrf_state_machine_step(
+            self._h, rows, C.byref(sm_cfg), self._arg(x_ee, (3, rows), "x_ee"), self._arg(start_goal, (3, rows), "start_goal"),
+            self._arg(blocks, (nb, 3, rows), "blocks"), nb, self._arg(q_gripper_io, (2, rows), "q_gripper_io"),
+            self._i32(sm_state, (abi.SM_NSTATE, rows), "sm_state"), self._arg(sm_goal, (abi.SM_NGOAL, rows), "sm_goal"),
+            self._arg(params_work, (abi.NPARAM, rows), "params_work"), int(skip_robot_mask), self._arg(act),
+            self._stream(stream))
+        self._check(rc)
+        return act
+
     def apply_action(self, q_io, qdot_io, action_io, vel_limit, stop_margin=-1.0, stream=None):
         """action := clip(action, +-vel_limit); q += dt*action; qdot := action  (EXJ:452-453)."""
         rows = q_io.shape[1]
@@ -332,7 +363,10 @@ class ControlLoop:
     monitor only.  State (q, qdot, deadlock state) lives in this object's device tensors and is advanced in place."""
 
     def __init__(self, h_action, h_rollout, q, qdot, params, vel_limit, deadlock=True, apply_estimate=True,
-                 stop_margin=1e-3, sm_state=None, use_graph=True):
+                 stop_margin=1e-3, sm_state=None, use_graph=True, pick_place=None):
+        """pick_place: dict(start_goal [3,rows], blocks [nb,3,rows] (already lifted by 0.1, EXJ:303), nr_blocks,
+        q_gripper [2,rows], model=1, h_grasp=None) -- runs the pick-and-place state machine on the device every step
+        (mrf_episode_set_pick_place); its state is then in self.sm_state / self.sm_goal / self.q_gripper."""
         self.ha, self.hr = h_action, h_rollout
         if h_rollout is not None and (h_rollout.dtype != h_action.dtype or h_rollout.device != h_action.device or
                                       h_rollout.cfg.n_robots != h_action.cfg.n_robots):
@@ -362,12 +396,36 @@ class ControlLoop:
         if sm_state is not None and sm_state.device != h_action.device:
             raise MrfError(f"sm_state lives on {sm_state.device}, the handles on {h_action.device}")
         self.use_graph = bool(use_graph)
+        self.pick_place = None
+        if pick_place is not None:
+            pp = dict(pick_place)
+            h = h_action
+            self.start_goal = pp["start_goal"].contiguous()
+            self.blocks = pp["blocks"].contiguous()
+            self.q_gripper = pp["q_gripper"].clone().contiguous()
+            self.sm_cfg = h.state_machine_config(pp["nr_blocks"], model=pp.get("model", 1))
+            self.sm_state, self.sm_goal = h.state_machine_state(self.start_goal)
+            self.gripper_action = torch.zeros((2, rows), dtype=h.dtype, device=h.device)
+            self.h_grasp = pp.get("h_grasp")
+            self.action_grasp = torch.zeros_like(self.q) if self.h_grasp is not None else None
+            nb = self.blocks.shape[0]
+            h._arg(self.blocks, (nb, 3, rows), "blocks")
+            h._arg(self.q_gripper, (2, rows), "q_gripper")
+            self.pick_place = True
         self.dl_cfg = h_action.deadlock_config() if (deadlock and h_rollout is not None) else None
         self.dl_state, self.dl_goal = (h_rollout.deadlock_state(self.n_scen) if self.dl_cfg is not None else (None, None))
 
     def run(self, n_steps, stream=None):
         ha, hr = self.ha, self.hr
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        # (re)attach this loop's pick-and-place buffers: the attachment lives in the action handle, which loops may share
+        if self.pick_place:
+            ha._check(ha.lib.mrf_episode_set_pick_place(
+                ha._h, C.byref(self.sm_cfg), p(self.start_goal), p(self.blocks), self.blocks.shape[0], p(self.q_gripper),
+                p(self.sm_state), p(self.sm_goal), p(self.gripper_action),
+                self.h_grasp._h if self.h_grasp is not None else None, p(self.action_grasp)))
+        else:
+            ha._check(ha.lib.mrf_episode_set_pick_place(ha._h, None, None, None, 0, None, None, None, None, None, None))
         rc = ha.lib.mrf_episode_run(hr._h if hr is not None else None, ha._h, self.n_scen, int(n_steps),
                                     C.byref(self.dl_cfg) if self.dl_cfg is not None else None, int(self.apply_estimate),
                                     self.vel_limit, self.stop_margin, p(self.q), p(self.qdot), p(self.params),
