@@ -133,26 +133,30 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
     panda_solve_row<LS, LO && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          // fold the spheres of every other robot from the LOCAL exchange buffer (step k's generation)
-#pragma unroll 1
-          for (int d = 1; d < N; ++d) {
-            int jr = me + d;
-            if (jr >= N) jr -= N;
-#pragma unroll 1
-            for (int slot = 0; slot < SX; ++slot) {
-              const int s = LO ? lo_sphere(slot, m01, m45) : slot;
-              const T mult = LO ? T(lo_count(slot, m01, m45)) : T(1);
-              const T* src = xloc + ((size_t)(jr * SX + slot) * 9) * V.b_max + scen;
-              T x[3], v[3], a[3];
+          // fold the spheres of every other robot from the LOCAL exchange buffer (step k's generation), one flat
+          // software-pipelined loop over (other robot, slot) pairs
+          pipelined_pairs<T, 9>(
+              (N - 1) * SX,
+              [&](int m, T (&buf)[9]) {
+                const int d = m / SX, slot = m - d * SX;
+                int jr = me + 1 + d;
+                if (jr >= N) jr -= N;
+                const T* src = xloc + ((size_t)(jr * SX + slot) * 9) * V.b_max + scen;
 #pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                x[c] = src[(size_t)c * V.b_max];
-                v[c] = dyn ? src[(size_t)(3 + c) * V.b_max] : T(0);
-                a[c] = dyn ? src[(size_t)(6 + c) * V.b_max] : T(0);
-              }
-              accumulate_obstacle<typename LS::Collision>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc, mult);
-            }
-          }
+                for (int c = 0; c < 9; ++c) buf[c] = src[(size_t)c * V.b_max];
+              },
+              [&](int m, T (&buf)[9]) {
+                const int slot = m % SX;
+                const int s = LO ? lo_sphere(slot, m01, m45) : slot;
+                const T mult = LO ? T(lo_count(slot, m01, m45)) : T(1);
+                T v[3], a[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  v[c] = dyn ? buf[3 + c] : T(0);
+                  a[c] = dyn ? buf[6 + c] : T(0);
+                }
+                accumulate_obstacle<typename LS::Collision>(cfg, E, buf, v, a, cfg.sphere_r[s], false, acc, mult);
+              });
         },
         qdd, act,
         [&](const PandaKin<T>& K1) {

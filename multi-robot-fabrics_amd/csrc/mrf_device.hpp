@@ -986,6 +986,25 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
   panda_finish_row<LS>(cfg, R, prm, K, E, acc, qdd, act);
 }
 
+// Software pipeline of depth one for loops whose operands come from memory while a single wave per SIMD has nothing
+// else to overlap the load latency with: the operands of item m+1 are fetched into the other register buffer before
+// item m is folded (loop unrolled by two, ping-pong buffers, no copies).  fetch(m, buf) loads, fold(m, buf) consumes.
+template <typename T, int NV, class Fetch, class Fold>
+__device__ __forceinline__ void pipelined_pairs(int n, Fetch fetch, Fold fold) {
+  if (n <= 0) return;
+  T A[NV], B[NV];
+  fetch(0, A);
+  int m = 0;
+#pragma unroll 1
+  for (; m + 1 < n; m += 2) {
+    fetch(m + 1, B);
+    fold(m, A);
+    fetch(m + 2 < n ? m + 2 : m + 1, A);  // past the end: re-reads the last item, never folded
+    fold(m + 1, B);
+  }
+  if (m < n) fold(m, A);
+}
+
 // ------------------------------------------------------------------------------------ link-origin sphere table
 // slot of link-origin sphere sp (0..7) in the tile once coincident spheres are merged (DevCfg::lo_merge*)
 __host__ __device__ __forceinline__ int lo_slot(int sp, int m01, int m45) { return sp - (sp >= 1 ? m01 : 0) - (sp >= 5 ? m45 : 0); }

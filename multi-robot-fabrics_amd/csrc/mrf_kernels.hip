@@ -25,12 +25,42 @@
 
 namespace mrf {
 
+// The thread-per-row kernels whose obstacle loop streams from HBM / L2 can be built for two waves per SIMD
+// (<= 256 registers, two-phase walk) so that one wave's loads overlap the other's arithmetic: experiment switches
+// -DMRF_OCC2_ACTION / _CART / _STEP (tools/build_variant.sh), measured by tools/prof_kernels.py.
+#define MRF_WPE2 __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifdef MRF_OCC2_ACTION
+#define MRF_ATTR_ACTION MRF_WPE2
+constexpr bool kActionSingleWalk = false;
+#else
+#define MRF_ATTR_ACTION
+constexpr bool kActionSingleWalk = true;
+#endif
+#ifdef MRF_OCC2_STEP
+#define MRF_ATTR_STEP MRF_WPE2
+constexpr bool kStepSingleWalk = false;
+#else
+#define MRF_ATTR_STEP
+constexpr bool kStepSingleWalk = true;
+#endif
+#ifdef MRF_OCC2_CART
+#define MRF_ATTR_CART MRF_WPE2
+#else
+#define MRF_ATTR_CART
+#endif
+#ifdef MRF_CART_TWO_WALKS
+constexpr bool kCartSingleWalk = false;
+#else
+constexpr bool kCartSingleWalk = true;
+#endif
+
 // obstacle loop over HBM arrays [n_obst][3][rows] (compute_action / Cartesian rollout); tk = elapsed obstacle time
 template <class CL, typename T>
 __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int64_t rows, int64_t r, int n_obst,
                                                       int n_static, const T* __restrict__ ox, const T* __restrict__ ov,
                                                       const T* __restrict__ oa, const T* __restrict__ orad, T tk,
                                                       bool allow_planar, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#ifdef MRF_NO_ARRAY_PREFETCH
 #pragma unroll 1
   for (int m = 0; m < n_obst; ++m) {
     const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
@@ -45,11 +75,41 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
     accumulate_obstacle<CL>(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r],
                             allow_planar && !is_static && cfg.obst_dim == 2, acc);
   }
+#else
+  // buf: x[3], v[3], a[3], radius.  Missing arrays (NULL) and static obstacles read x in their place and are zeroed in
+  // the fold, so that the fetch is the same ten loads for every obstacle (no divergent address arithmetic).
+  const T* pv = ov ? ov : ox;
+  const T* pa = oa ? oa : ox;
+  pipelined_pairs<T, 10>(
+      n_obst,
+      [&](int m, T (&buf)[10]) {
+        const int64_t base = (int64_t)(m * 3) * rows + r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          buf[c] = ox[base + c * rows];
+          buf[3 + c] = pv[base + c * rows];
+          buf[6 + c] = pa[base + c * rows];
+        }
+        buf[9] = orad[(int64_t)m * rows + r];
+      },
+      [&](int m, T (&buf)[10]) {
+        const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
+        const bool has_v = ov && !is_static, has_a = oa && !is_static;
+        T xo[3], vo[3], ao[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vo[c] = has_v ? buf[3 + c] : T(0);
+          xo[c] = buf[c] + tk * vo[c];  // Cartesian rollout: x += dt*v per step (FPC:448-453); tk = 0 otherwise
+          ao[c] = has_a ? buf[6 + c] : T(0);
+        }
+        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[9], allow_planar && !is_static && cfg.obst_dim == 2, acc);
+      });
+#endif
 }
 
 // ---------------------------------------------------------------------------- compute_action
 template <typename T, class LS>
-__global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+__global__ __launch_bounds__(256) MRF_ATTR_ACTION void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                        const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ prm, int n_obst, int n_static,
                                                        const T* __restrict__ ox, const T* __restrict__ ov,
@@ -62,7 +122,7 @@ __global__ __launch_bounds__(256) void k_action_panda(const DevCfg<T>* __restric
   load_state(rows, r, q, qd, R);
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   T qdd[7], act[7];
-  panda_solve_row<LS, true>(
+  panda_solve_row<LS, kActionSingleWalk>(
       cfg, cfg.mount[(int)(r % cfg.n_robots)], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
         obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E, acc);
@@ -666,15 +726,16 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
 
 // ---------------------------------------------------------------------------- Cartesian rollout
 template <typename T, class LS>
-__global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+__global__ __launch_bounds__(256) MRF_ATTR_CART void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
                                                              const T* __restrict__ prm, int n_obst, int n_static,
                                                              const T* __restrict__ ox0, const T* __restrict__ ov,
                                                              const T* __restrict__ oa, const T* __restrict__ orad,
                                                              T* __restrict__ avg_out, T* __restrict__ traj_q,
                                                              T* __restrict__ traj_qd) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = r < rows;  // the tail lanes shadow the last row (wave-wide votes below), without stores
+  if (!active) r = rows - 1;
   const DevCfg<T>& cfg = *cfgp;
   PandaState<T> R;
   load_state(rows, r, q0, qd0, R);
@@ -686,35 +747,53 @@ __global__ __launch_bounds__(256) void k_rollout_cart_panda(const DevCfg<T>* __r
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
     T qdd[7], act[7];
-    panda_solve_row<LS, false>(
+    panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc);
         },
         qdd, act);
+    // system_step (FPC:77-92); cos q / sin q advance by the angle-sum formula while every |dq| of the wave is small
+    T dq[7];
+    bool small = true;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       if (cfg.mode == MRF_MODE_VEL) {
         R.qd[j] = act[j];
-        R.q[j] += cfg.dt * R.qd[j];
+        dq[j] = cfg.dt * R.qd[j];
       } else {
-        R.q[j] += cfg.dt * R.qd[j] + T(0.5) * cfg.dt * cfg.dt * act[j];
+        dq[j] = cfg.dt * R.qd[j] + T(0.5) * cfg.dt * cfg.dt * act[j];
         R.qd[j] += cfg.dt * act[j];
       }
+      R.q[j] += dq[j];
+      small = small && (m_abs(dq[j]) < T(0.125));
       sumsq += R.qd[j] * R.qd[j];
-      m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
     }
-    if (traj_q) {
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T sd, cd;
+        small_sincos(dq[j], sd, cd);
+        const T c = R.cq[j] * cd - R.sq[j] * sd;
+        const T sn = R.sq[j] * cd + R.cq[j] * sd;
+        R.cq[j] = c;
+        R.sq[j] = sn;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    }
+    if (active && traj_q) {
 #pragma unroll
       for (int j = 0; j < 7; ++j) traj_q[((int64_t)k * 7 + j) * rows + r] = R.q[j];
     }
-    if (traj_qd) {
+    if (active && traj_qd) {
 #pragma unroll
       for (int j = 0; j < 7; ++j) traj_qd[((int64_t)k * 7 + j) * rows + r] = R.qd[j];
     }
     tk += cfg.dt;
   }
-  avg_out[r] = sumsq / (T)(H * 7);
+  if (active) avg_out[r] = sumsq / (T)(H * 7);
 }
 
 // ---------------------------------------------------------------------------- sphere kinematics
@@ -813,7 +892,7 @@ struct RobotSlots {
   int s[MRF_MAX_ROBOTS];
 };
 template <typename T, class LS>
-__global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
+__global__ __launch_bounds__(256) MRF_ATTR_STEP void k_step_action(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int robot_first,
                                                       int robot_count, const T* __restrict__ q, T* __restrict__ qd_io,
                                                       const T* __restrict__ prm, const T* __restrict__ sph_all,
                                                       RobotSlots slots, T* __restrict__ sumsq_io) {
@@ -831,29 +910,34 @@ __global__ __launch_bounds__(256) void k_step_action(const DevCfg<T>* __restrict
   const int m01 = cfg.lo_merge01, m45 = cfg.lo_merge45;
   const int SX = cfg.n_spheres - m01 - m45;  // == mrf_exchange_spheres()
   T qdd[7], act[7];
-  panda_solve_row<LS, true>(
+  panda_solve_row<LS, kStepSingleWalk>(
       cfg, cfg.mount[me], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-#pragma unroll 1
-        for (int d = 1; d < N; ++d) {
-          int jr = me + d;
-          if (jr >= N) jr -= N;
-#pragma unroll 1
-          for (int slot = 0; slot < SX; ++slot) {
-            // exchanged slots: coincident link origins (DevCfg::lo_merge*) arrive once and count twice
-            const int s = lo_sphere(slot, m01, m45);
-            const T mult = T(lo_count(slot, m01, m45));
-            const int64_t base = ((int64_t)(slots.s[jr] * SX + slot) * 9) * n_scen + scen;
-            T x[3], v[3], a[3];
+        // (other robot, exchanged slot) pairs in one flat, software-pipelined loop: the next sphere's nine scalars
+        // are in flight while the current one is folded.  Coincident link origins (DevCfg::lo_merge*) arrive once
+        // and count twice.
+        const bool dyn = cfg.dynamic != 0;
+        pipelined_pairs<T, 9>(
+            (N - 1) * SX,
+            [&](int m, T (&buf)[9]) {
+              const int d = m / SX, slot = m - d * SX;
+              int jr = me + 1 + d;
+              if (jr >= N) jr -= N;
+              const T* src = sph_all + ((int64_t)(slots.s[jr] * SX + slot) * 9) * n_scen + scen;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              x[c] = sph_all[base + (int64_t)c * n_scen];
-              v[c] = cfg.dynamic ? sph_all[base + (int64_t)(3 + c) * n_scen] : T(0);
-              a[c] = cfg.dynamic ? sph_all[base + (int64_t)(6 + c) * n_scen] : T(0);
-            }
-            accumulate_obstacle<typename LS::Collision>(cfg, E, x, v, a, cfg.sphere_r[s], false, acc, mult);
-          }
-        }
+              for (int c = 0; c < 9; ++c) buf[c] = src[(int64_t)c * n_scen];
+            },
+            [&](int m, T (&buf)[9]) {
+              const int slot = m % SX;
+              T v[3], a[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                v[c] = dyn ? buf[3 + c] : T(0);
+                a[c] = dyn ? buf[6 + c] : T(0);
+              }
+              accumulate_obstacle<typename LS::Collision>(cfg, E, buf, v, a, cfg.sphere_r[lo_sphere(slot, m01, m45)], false, acc,
+                                                          T(lo_count(slot, m01, m45)));
+            });
       },
       qdd, act);
   T ss = T(0);
