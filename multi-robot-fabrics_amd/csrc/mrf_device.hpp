@@ -989,6 +989,8 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
 // Software pipeline of depth one for loops whose operands come from memory while a single wave per SIMD has nothing
 // else to overlap the load latency with: the operands of item m+1 are fetched into the other register buffer before
 // item m is folded (loop unrolled by two, ping-pong buffers, no copies).  fetch(m, buf) loads, fold(m, buf) consumes.
+// Deeper rings (3..6 buffers, loop unrolled by the depth) were measured and lose: the extra buffers push the solve
+// into scratch (k_action_panda 0.20 ms at depth one, 0.28 / 0.33 / 0.34 / 0.57 ms as rings of 2 / 3 / 4 / 6).
 template <typename T, int NV, class Fetch, class Fold>
 __device__ __forceinline__ void pipelined_pairs(int n, Fetch fetch, Fold fold) {
   if (n <= 0) return;

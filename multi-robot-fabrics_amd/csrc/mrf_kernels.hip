@@ -896,6 +896,11 @@ __global__ __launch_bounds__(256) MRF_ATTR_STEP void k_step_action(const DevCfg<
                                                       int robot_count, const T* __restrict__ q, T* __restrict__ qd_io,
                                                       const T* __restrict__ prm, const T* __restrict__ sph_all,
                                                       RobotSlots slots, T* __restrict__ sumsq_io) {
+  // robot -> block position of sph_all, staged in LDS: the lookup is per lane (each lane has its own "other robot"),
+  // and an LDS read does not drain the vector-memory queue the prefetched sphere loads sit in
+  __shared__ int slot_of[MRF_MAX_ROBOTS];
+  if (threadIdx.x < MRF_MAX_ROBOTS) slot_of[threadIdx.x] = slots.s[threadIdx.x];
+  __syncthreads();
   const DevCfg<T>& cfg = *cfgp;
   const int64_t rows = n_scen * robot_count;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(256) MRF_ATTR_STEP void k_step_action(const DevCfg<
               const int d = m / SX, slot = m - d * SX;
               int jr = me + 1 + d;
               if (jr >= N) jr -= N;
-              const T* src = sph_all + ((int64_t)(slots.s[jr] * SX + slot) * 9) * n_scen + scen;
+              const T* src = sph_all + ((int64_t)(slot_of[jr] * SX + slot) * 9) * n_scen + scen;
 #pragma unroll
               for (int c = 0; c < 9; ++c) buf[c] = src[(int64_t)c * n_scen];
             },
