@@ -95,6 +95,19 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
 
     ncores = os.cpu_count() or 1
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncores
+    quota = None          # a container can list every core and still be throttled to a few by its cgroup CPU quota
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    quota = None if int(txt[0]) < 0 else int(txt[0]) / float(f2.read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
     nmax = batch["q"].shape[1] // N
     # thread-count sweep on small samples (the box's usable cores can be fewer than it lists), then one bounded
     # sample at the best count and one on a single thread
@@ -119,6 +132,7 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
                   f"float64 C++ restatement (oracle/mrf_oracle.cpp, -O3 -march=native, OpenMP one scenario per thread); "
                   f"thread count chosen by a sweep over {cands}",
         "single_thread_value": out["single"]["rate"], "host_cores": ncores, "sched_getaffinity_cores": usable,
+        "cgroup_cpu_quota_cores": quota,
         "thread_sweep_control_steps_per_s": {str(k): v for k, v in probe.items()},
         "rollout_steps_per_s": best["rate"] * N * H,
     }
