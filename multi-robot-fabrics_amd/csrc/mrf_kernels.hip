@@ -297,6 +297,60 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
   if (m < M) accumulate_obstacle<CL>(cfg, E, bufA, bufA + 3, bufA + 6, bufA[9], false, acc, bufA[10]);  // odd count
 }
 
+// Generic sphere tables (offset spheres, any count): every lane walks ITS OWN chain once, emitting its spheres in
+// table order; they are exchanged CH at a time through a [CH][9][64] LDS tile (18 KB in f64) and each lane folds the
+// chunk's spheres of the other robots of its scenario before the walk moves on -- instead of every lane re-walking all
+// N-1 other chains (r01).  The full sphere set of 64 lanes would not fit the LDS at four waves per CU (20 spheres: 92 KB
+// per wave), a chunk does.  xch holds cos q, sin q, qdot of every lane ([21][64], the rolled walk reads them by joint
+// index); chunk is the exchange tile.  acc_scale: jsign for x-dot-dot = jac_dot*qdot (rollouts, FPJ:97-99), 0 where the
+// reference passes zero accelerations (EXJ:411).
+constexpr int GEN_CH = 4;
+constexpr int GEN_XCH = 21 * 64;
+constexpr int GEN_SCALARS = GEN_XCH + GEN_CH * 9 * 64;
+
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_generic_chunked(const DevCfg<T>& cfg, T* __restrict__ xch, int lane, int ls, int li,
+                                                          int N, const T* __restrict__ mount_own, bool dyn, T acc_scale,
+                                                          const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  T* chunk = xch + GEN_XCH;
+  const int S = cfg.n_spheres;
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  panda_walk_spheres<false, T>(
+      cfg, mount_own,
+      [&](int j, T& c, T& s, T& qdj) {
+        c = xch[(3 * j + 0) * 64 + lane];
+        s = xch[(3 * j + 1) * 64 + lane];
+        qdj = xch[(3 * j + 2) * 64 + lane];
+      },
+      [&](int s, const T* x, const T* v, const T* a) {
+        const int k = s % GEN_CH;
+        if (k == 0) __syncthreads();  // the previous chunk has been folded by every lane
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          chunk[((k * 9) + c) * 64 + lane] = x[c];
+          chunk[((k * 9) + 3 + c) * 64 + lane] = dyn ? v[c] : T(0);          // FPJ:215-220 / EXJ:336-339
+          chunk[((k * 9) + 6 + c) * 64 + lane] = dyn ? acc_scale * a[c] : T(0);
+        }
+        if (k != GEN_CH - 1 && s != S - 1) return;
+        __syncthreads();
+        const int n = k + 1, s0 = s - k;  // spheres in this chunk, first sphere of the chunk
+        pipelined_pairs<T, 9>(
+            (N - 1) * n,
+            [&](int m, T (&buf)[9]) {
+              const int d = m / n, kk = m - d * n;
+              int jr = li + 1 + d;
+              if (jr >= N) jr -= N;
+              lds_ptr src = (lds_ptr)(chunk + (kk * 9) * 64 + ls * N + jr);
+#pragma unroll
+              for (int c = 0; c < 9; ++c) buf[c] = src[c * 64];
+            },
+            [&](int m, T (&buf)[9]) {
+              const int kk = m % n;
+              accumulate_obstacle<CL>(cfg, E, buf, buf + 3, buf + 6, cfg.sphere_r[s0 + kk], false, acc);
+            });
+      });
+}
+
 // ---------------------------------------------------------------------------- coupled joint-space rollout
 // One wave per block.  Lanes are (scenario, robot) pairs with the N robots of a scenario adjacent, so the
 // exchange step of the recurrence (FPJ:211-225: every robot needs every other robot's spheres at step k)
@@ -308,7 +362,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
                                                        T* __restrict__ traj_q, T* __restrict__ traj_qd) {
-  __shared__ T xch[LO ? TILE_SCALARS : 21 * 64];
+  __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
   const DevCfg<T>& cfg = *cfgp;
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
@@ -391,28 +445,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
       panda_solve_row<LS, false>(
           cfg, mount_own, R, P,
           [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-#pragma unroll 1
-            for (int d = 1; d < N; ++d) {
-              int jr = li + d;
-              if (jr >= N) jr -= N;
-              const int src = ls * N + jr;
-              panda_walk_spheres<false, T>(
-                  cfg, cfg.mount[jr],
-                  [&](int j, T& c, T& s, T& qdj) {
-                    c = xch[(3 * j + 0) * 64 + src];
-                    s = xch[(3 * j + 1) * 64 + src];
-                    qdj = xch[(3 * j + 2) * 64 + src];
-                  },
-                  [&](int s, const T* x, const T* v, const T* a) {
-                    T vv[3], aa[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                      vv[c] = cfg.dynamic ? v[c] : T(0);              // FPJ:215-220
-                      aa[c] = cfg.dynamic ? cfg.jsign * a[c] : T(0);  // jac_dot_fun @ qdot, FPJ:97-99 + utils.py:28
-                    }
-                    accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
-                  });
-            }
+            obstacles_generic_chunked<typename LS::Collision>(cfg, xch, lane, ls, li, N, mount_own, cfg.dynamic != 0, cfg.jsign, E, acc);
           },
           qdd, act);
     }
@@ -443,7 +476,7 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
                                                         const T* __restrict__ q, const T* __restrict__ qd,
                                                         const T* __restrict__ prm, int use_accel,
                                                         T* __restrict__ qdd_out, T* __restrict__ act_out) {
-  __shared__ T xch[LO ? TILE_SCALARS : 21 * 64];
+  __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
   const DevCfg<T>& cfg = *cfgp;
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
@@ -485,28 +518,8 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
     panda_solve_row<LS, false>(
         cfg, cfg.mount[li], R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-#pragma unroll 1
-          for (int d = 1; d < N; ++d) {
-            int jr = li + d;
-            if (jr >= N) jr -= N;
-            const int src = ls * N + jr;
-            panda_walk_spheres<false, T>(
-                cfg, cfg.mount[jr],
-                [&](int j, T& c, T& s, T& qdj) {
-                  c = xch[(3 * j + 0) * 64 + src];
-                  s = xch[(3 * j + 1) * 64 + src];
-                  qdj = xch[(3 * j + 2) * 64 + src];
-                },
-                [&](int s, const T* x, const T* v, const T* a) {
-                  T vv[3], aa[3];
-#pragma unroll
-                  for (int c = 0; c < 3; ++c) {
-                    vv[c] = cfg.dynamic ? v[c] : T(0);                            // EXJ:336-339
-                    aa[c] = (cfg.dynamic && use_accel) ? cfg.jsign * a[c] : T(0);  // EXJ:411 passes zeros
-                  }
-                  accumulate_obstacle<typename LS::Collision>(cfg, E, x, vv, aa, cfg.sphere_r[s], false, acc);
-                });
-          }
+          obstacles_generic_chunked<typename LS::Collision>(cfg, xch, lane, ls, li, N, cfg.mount[li], cfg.dynamic != 0,
+                                                            use_accel ? cfg.jsign : T(0), E, acc);  // EXJ:411 passes zeros
         },
         qdd, act);
   }
