@@ -171,6 +171,8 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     out = {}
     a = copy.copy(args)
     a.steps, a.warmup = max(1, min(args.steps, 10)), 1
+    if world > 1:       # the ranks of a robot group work on the same scenarios: one batch per replica, made once
+        batch = ShardedRollout.replica_batch(cfg_roll, args.scenarios, rank, world)
     for transport in ("rccl", "peer"):
         a.transport = transport
         try:

@@ -179,10 +179,9 @@ class ShardedRollout:
         B = args.scenarios
         transport = getattr(args, "transport", "rccl")
         sr = ShardedRollout(cfg, rank, world, device_index=local_rank, transport=transport, max_scenarios=B)
-        if world > 1 or batch is None:
+        if batch is None:
             # the ranks of one robot group work on the SAME scenarios (one batch per replica)
-            from . import scenarios
-            batch = scenarios.panda_batch(cfg, B, seed=1000 + sr.replica)
+            batch = ShardedRollout.replica_batch(cfg, B, rank, world)
         rows = sr.own_rows(B).numpy()
         h = sr.backend.h
         q0, qd0, prm = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
@@ -238,6 +237,12 @@ class ShardedRollout:
                                        "ok": perr <= (1e-9 if cfg.scalar == abi.F64 else 2e-3), "scenarios": nchk},
             "roofline": ShardedRollout.roofline(cfg, sr, B, sb, elapsed / args.steps),
         }
+
+    @staticmethod
+    def replica_batch(cfg, B, rank, world):
+        from . import scenarios
+        G, _ = robot_groups(cfg.n_robots, world)
+        return scenarios.panda_batch(cfg, B, seed=1000 + rank // G)
 
     @staticmethod
     def roofline(cfg, sr, B, sb, seconds_per_rollout):
