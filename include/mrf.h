@@ -169,6 +169,25 @@ int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const voi
 int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot, void* x_out, void* v_out,
                    void* a_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Host-buffer entry points: the same four calls for callers that hold HOST arrays of one (or a few) scenarios, as the
+ * reference's call sites do (numpy in, numpy out: example_pandas_Jointspace.py:374,441; example_pandas_cartesian.py:404).
+ * All arrays are float64 host memory in the layout of the device versions; the library packs them into a pinned staging
+ * buffer of the handle, moves them with one copy each way on its own stream and returns after that stream has been
+ * synchronised (so these calls are synchronous; results are valid on return).  Optional arrays as in the device
+ * versions (NULL = absent). */
+int mrf_compute_action_host(mrf_handle* h, int64_t rows, const double* q, const double* qdot, const double* params,
+                            int32_t n_obst, int32_t n_obst_static, const double* obst_x, const double* obst_v,
+                            const double* obst_a, const double* obst_r, double* qddot_out, double* action_out);
+int mrf_rollout_host(mrf_handle* h, int64_t n_scenarios, const double* q0, const double* qdot0, const double* params,
+                     double* avg_vel_out, double* traj_q, double* traj_qdot);
+int mrf_rollout_cartesian_host(mrf_handle* h, int64_t rows, const double* q0, const double* qdot0, const double* params,
+                               int32_t n_obst, int32_t n_obst_static, const double* obst_x0, const double* obst_v,
+                               const double* obst_a, const double* obst_r, double* avg_vel_out, double* traj_q,
+                               double* traj_qdot);
+int mrf_fk_spheres_host(mrf_handle* h, int64_t rows, const double* q, const double* qdot, double* x_out, double* v_out,
+                        double* a_out);
+
 /* Robot-sharded rollout (one or a few robots per GPU).  One rollout step is
  *   mrf_step_predict : q += dt*qdot for the owned robots; writes their spheres (x,v,a)
  *   <all-gather of the sphere block across ranks -- done by the host over RCCL>

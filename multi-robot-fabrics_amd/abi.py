@@ -80,6 +80,7 @@ EXPORTS = [
     "mrf_fk_spheres", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
+    "mrf_compute_action_host", "mrf_rollout_host", "mrf_rollout_cartesian_host", "mrf_fk_spheres_host",
     "mrf_default_state_machine_config", "mrf_state_machine_config_sizeof", "mrf_state_machine_init", "mrf_state_machine_step",
     "mrf_episode_set_pick_place",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
@@ -186,6 +187,14 @@ def load_library(path=None):
     lib.mrf_episode_run.argtypes = [vp, vp, i64, i32, dlp, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, vp, vp,
                                     vp, vp, vp, vp, vp, i32, vp]
     lib.mrf_episode_run.restype = C.c_int
+    lib.mrf_compute_action_host.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mrf_compute_action_host.restype = C.c_int
+    lib.mrf_rollout_host.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.mrf_rollout_host.restype = C.c_int
+    lib.mrf_rollout_cartesian_host.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_rollout_cartesian_host.restype = C.c_int
+    lib.mrf_fk_spheres_host.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.mrf_fk_spheres_host.restype = C.c_int
     smp = C.POINTER(StateMachineConfig)
     lib.mrf_default_state_machine_config.argtypes = [smp, i32]
     lib.mrf_default_state_machine_config.restype = None

@@ -35,6 +35,7 @@ struct mrf_handle {
     uint64_t grasp_serial = 0;
     void* action_grasp = nullptr;
   } pp;
+  void* staging = nullptr;  // pinned + device staging buffers and the stream of the host-buffer entry points (mrf_hostpath.hip)
   void* comm = nullptr;   // robot-sharded rollout state (mrf_comm.hip): communicator / mapped peer buffers / work buffers
 };
 
@@ -120,6 +121,8 @@ int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_
                       void* stream);
 // frees h->comm (mrf_comm.hip); called by mrf_destroy
 void comm_release(mrf_handle* h);
+// frees h->staging (mrf_hostpath.hip); called by mrf_destroy
+void staging_release(mrf_handle* h);
 
 }  // namespace mrf_host
 

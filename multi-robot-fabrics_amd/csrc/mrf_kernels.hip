@@ -1230,6 +1230,7 @@ void mrf_destroy(mrf_handle* h) {
   if (!h) return;
   mrf_host::DeviceGuard guard(h->dcfg ? h->device : -1);
   mrf_host::comm_release(h);
+  mrf_host::staging_release(h);
   if (h->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)h->graph_exec);
   if (h->own_stream) (void)hipStreamDestroy((hipStream_t)h->own_stream);
   if (h->dcfg) (void)hipFree(h->dcfg);

@@ -136,11 +136,9 @@ class _SphereEvaluator:
 
     def eval(self, q_rows, qd_rows=None):
         """q_rows [rows,7] -> x, v, a  each [S,3,rows] numpy (v, a None without qd)."""
-        h = self.h
-        q = h.tensor(np.ascontiguousarray(np.asarray(q_rows, dtype=float)[:, :7].T))
-        qd = None if qd_rows is None else h.tensor(np.ascontiguousarray(np.asarray(qd_rows, dtype=float)[:, :7].T))
-        x, v, a = h.fk_spheres(q, qd)
-        return (x.cpu().numpy(), None if v is None else v.cpu().numpy(), None if a is None else a.cpu().numpy())
+        q = np.ascontiguousarray(np.asarray(q_rows, dtype=float)[:, :7].T)
+        qd = None if qd_rows is None else np.ascontiguousarray(np.asarray(qd_rows, dtype=float)[:, :7].T)
+        return self.h.fk_spheres_host(q, qd)          # numpy in, numpy out (mrf_fk_spheres_host)
 
 
 def _vec(q):

@@ -275,12 +275,28 @@ class ParameterizedFabricPlanner:
             v = np.asarray(val, dtype=float).reshape(-1)
             dst[row, :len(v)] = v[:3]
 
-        for j in range(ns):
-            put(ox, j, xs[j])
-            orad[j] = float(np.asarray(rs[j]).reshape(-1)[0])
-        for j in range(nd):
-            put(ox, ns + j, xd[j]); put(ov, ns + j, vd[j]); put(oa, ns + j, ad[j])
-            orad[ns + j] = float(np.asarray(rd[j]).reshape(-1)[0])
+        def block(dst, lo, vals):
+            """all entries at once when they are uniform vectors (the usual case), entry by entry otherwise"""
+            try:
+                a = np.asarray(vals, dtype=float).reshape(len(vals), -1)
+                dst[lo:lo + len(vals), :min(3, a.shape[1])] = a[:, :3]
+            except ValueError:
+                for j, v in enumerate(vals):
+                    put(dst, lo + j, v)
+
+        def radii(lo, vals):
+            try:
+                orad[lo:lo + len(vals)] = np.asarray(vals, dtype=float).reshape(len(vals), -1)[:, 0]
+            except ValueError:
+                for j, v in enumerate(vals):
+                    orad[lo + j] = float(np.asarray(v).reshape(-1)[0])
+
+        if ns:
+            block(ox, 0, xs)
+            radii(0, rs)
+        if nd:
+            block(ox, ns, xd); block(ov, ns, vd); block(oa, ns, ad)
+            radii(ns, rd)
         return ox, ov, oa, orad, ns
 
     def compute_action(self, **kwargs):
@@ -294,12 +310,13 @@ class ParameterizedFabricPlanner:
         prm = self.params_row(kwargs)
         ox, ov, oa, orad, ns = self.obstacle_arrays(kwargs)
         M = ox.shape[0]
+        # host arrays in, host array out: one packed copy each way inside the library (mrf_compute_action_host)
         if M:
-            args = h.upload(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None], oa[:, :, None], orad[:, None])
+            act = h.compute_action_host(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None], oa[:, :, None],
+                                        orad[:, None], n_static=ns)
         else:
-            args = h.upload(q[:, None], qd[:, None], prm[:, None])
-        act = h.compute_action(*args, n_static=ns)
-        return act[:, 0].cpu().numpy().astype(np.float64)
+            act = h.compute_action_host(q[:, None], qd[:, None], prm[:, None])
+        return act[:, 0].copy()
 
     # ------------------------------------------------------------------ kinematics access (EXJ:235, utils.py:35)
     def get_forward_kinematics(self, link_name, position_only=True):

@@ -123,20 +123,18 @@ class ForwardFabricsPlanner:
     def _run(self, inputs_action, traj):
         if self._handle is None:
             raise RuntimeError("call forward_multi_fabrics_symbolic() first")
-        h = self._handle
-        q, qd, prm = h.upload(*self._rows(inputs_action))
-        return h.rollout(q, qd, prm, want_traj=traj)
+        q, qd, prm = self._rows(inputs_action)
+        return self._handle.rollout_host(q, qd, prm, want_traj=traj)      # numpy in, numpy out (mrf_rollout_host)
 
     # -- the reference's entry points --------------------------------------------------------------------------------
     def get_velocity_rollouts(self, inputs_action):
         """-> list over robots of np.ndarray shape (1,): mean squared joint velocity over the horizon (FPJ:298-336)."""
-        avg = self._run(inputs_action, traj=False).cpu().numpy().astype(np.float64)
+        avg = self._run(inputs_action, traj=False)
         return [avg[i:i + 1].copy() for i in range(self.nr_robots)]
 
     def rollouts_numerical(self, inputs_action=None, **_ignored):
         """-> (q_N, q_dot_N, q_ddot_N): dicts 'robot_i' -> [ndarray(7, H)] (FPJ:338-423; q_ddot is zero, FPJ:202)."""
-        avg, tq, tqd = self._run(inputs_action, traj=True)
-        tq, tqd = tq.cpu().numpy(), tqd.cpu().numpy()         # [H, 7, N]
+        avg, tq, tqd = self._run(inputs_action, traj=True)     # [H, 7, N]
         qN, qdN, qddN = {}, {}, {}
         for i in range(self.nr_robots):
             qN["robot_%d" % i] = [tq[:, :, i].T.copy()]
@@ -319,21 +317,19 @@ class FabricsRollouts:
         h = self._handle
         q, qd, prm, ox, ov, oa, orad = self._unpack(arguments)
         if ox.shape[0]:
-            qt, qdt, pt, *obst = h.upload(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None],
-                                          oa[:, :, None], orad[:, None])
+            obst = (ox[:, :, None], ov[:, :, None], oa[:, :, None], orad[:, None])
         else:
-            qt, qdt, pt = h.upload(q[:, None], qd[:, None], prm[:, None])
             obst = (None, None, None, None)
-        return h.rollout_cartesian(qt, qdt, pt, *obst, want_traj=traj, n_static=self.nr_obsts)
+        return h.rollout_cartesian_host(q[:, None], qd[:, None], prm[:, None], *obst, want_traj=traj, n_static=self.nr_obsts)
 
     def get_velocity_rollouts(self, arguments):
         """-> DM-like array of shape (1,) whose .full() is (1,1), as `avg_vel_fun(*arguments)` (FPC:561-563)."""
-        return DM(self._run(arguments, traj=False).cpu().numpy().astype(np.float64))
+        return DM(self._run(arguments, traj=False))
 
     def rollouts_numerical(self, arguments):
         """-> q_N, q_dot_N, q_ddot_N each ndarray (7, H) (FPC:538-559; q_ddot is zero in mode 'vel', FPC:431)."""
         avg, tq, tqd = self._run(arguments, traj=True)
-        tq, tqd = tq.cpu().numpy()[:, :, 0].T.copy(), tqd.cpu().numpy()[:, :, 0].T.copy()
+        tq, tqd = tq[:, :, 0].T.copy(), tqd[:, :, 0].T.copy()
         if self.fabrics_mode == "vel":
             return tq, tqd, np.zeros_like(tq)
         qdd = np.diff(np.concatenate([np.asarray(self._unpack(arguments)[1])[:, None], tqd], axis=1), axis=1) / self.dt

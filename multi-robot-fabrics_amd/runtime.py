@@ -214,6 +214,88 @@ class FabricHandle:
         self._check(rc)
 
 
+    # ------------------------------------------------------------------ host-buffer entry points (numpy in, numpy out)
+    @staticmethod
+    def _host(a, shape, name):
+        """float64 C-contiguous numpy array of the given shape (converted if needed) -> (array, pointer)."""
+        import numpy as np
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != tuple(shape):
+            raise MrfError(f"{name}: expected shape {tuple(shape)}, got {a.shape}")
+        return a, C.c_void_p(a.ctypes.data)
+
+    def compute_action_host(self, q, qdot, params, obst_x=None, obst_v=None, obst_a=None, obst_r=None, n_static=0,
+                            want_qddot=False):
+        """compute_action for host arrays (layouts of compute_action): one packed copy each way inside the library, no
+        torch tensors -- the path of the reference-shaped single-scenario calls.  -> action [dof, rows] (numpy)."""
+        import numpy as np
+        q, pq = self._host(q, (self.dof, np.shape(q)[1]), "q")
+        rows = q.shape[1]
+        M = 0 if obst_x is None else np.shape(obst_x)[0]
+        qd, pqd = self._host(qdot, (self.dof, rows), "qdot")
+        prm, pp = self._host(params, (abi.NPARAM, rows), "params")
+        ox, pox = self._host(obst_x, (M, 3, rows), "obst_x")
+        ov, pov = self._host(obst_v, (M, 3, rows), "obst_v")
+        oa, poa = self._host(obst_a, (M, 3, rows), "obst_a")
+        orad, por = self._host(obst_r, (M, rows), "obst_r")
+        act = np.empty((self.dof, rows))
+        qdd = np.empty((self.dof, rows)) if want_qddot else None
+        rc = self.lib.mrf_compute_action_host(self._h, rows, pq, pqd, pp, M, n_static, pox, pov, poa, por,
+                                              None if qdd is None else C.c_void_p(qdd.ctypes.data), C.c_void_p(act.ctypes.data))
+        self._check(rc)
+        return (act, qdd) if want_qddot else act
+
+    def rollout_host(self, q0, qdot0, params, want_traj=False):
+        import numpy as np
+        q, pq = self._host(q0, (self.dof, np.shape(q0)[1]), "q0")
+        rows = q.shape[1]
+        N, H = self.cfg.n_robots, self.cfg.horizon
+        if rows % N:
+            raise MrfError("rows must be a multiple of n_robots")
+        qd, pqd = self._host(qdot0, (self.dof, rows), "qdot0")
+        prm, pp = self._host(params, (abi.NPARAM, rows), "params")
+        avg = np.empty((rows,))
+        tq = np.empty((H, self.dof, rows)) if want_traj else None
+        tqd = np.empty((H, self.dof, rows)) if want_traj else None
+        p = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        self._check(self.lib.mrf_rollout_host(self._h, rows // N, pq, pqd, pp, p(avg), p(tq), p(tqd)))
+        return (avg, tq, tqd) if want_traj else avg
+
+    def rollout_cartesian_host(self, q0, qdot0, params, obst_x0, obst_v, obst_a, obst_r, want_traj=False, n_static=0):
+        import numpy as np
+        q, pq = self._host(q0, (self.dof, np.shape(q0)[1]), "q0")
+        rows = q.shape[1]
+        H = self.cfg.horizon
+        M = 0 if obst_x0 is None else np.shape(obst_x0)[0]
+        qd, pqd = self._host(qdot0, (self.dof, rows), "qdot0")
+        prm, pp = self._host(params, (abi.NPARAM, rows), "params")
+        ox, pox = self._host(obst_x0, (M, 3, rows), "obst_x0")
+        ov, pov = self._host(obst_v, (M, 3, rows), "obst_v")
+        oa, poa = self._host(obst_a, (M, 3, rows), "obst_a")
+        orad, por = self._host(obst_r, (M, rows), "obst_r")
+        avg = np.empty((rows,))
+        tq = np.empty((H, self.dof, rows)) if want_traj else None
+        tqd = np.empty((H, self.dof, rows)) if want_traj else None
+        p = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        self._check(self.lib.mrf_rollout_cartesian_host(self._h, rows, pq, pqd, pp, M, n_static, pox, pov, poa, por,
+                                                        p(avg), p(tq), p(tqd)))
+        return (avg, tq, tqd) if want_traj else avg
+
+    def fk_spheres_host(self, q, qdot=None):
+        import numpy as np
+        q, pq = self._host(q, (self.dof, np.shape(q)[1]), "q")
+        rows = q.shape[1]
+        S = self.cfg.n_spheres
+        qd, pqd = self._host(qdot, (self.dof, rows), "qdot")
+        x = np.empty((S, 3, rows))
+        v = np.empty((S, 3, rows)) if qd is not None else None
+        a = np.empty((S, 3, rows)) if qd is not None else None
+        p = lambda t: None if t is None else C.c_void_p(t.ctypes.data)
+        self._check(self.lib.mrf_fk_spheres_host(self._h, rows, pq, pqd, p(x), p(v), p(a)))
+        return x, v, a
+
     # ------------------------------------------------------------------ robot-sharded rollout inside the library
     def comm_unique_id(self):
         """Rank 0 of a robot group: a fresh RCCL communicator id (bytes) to hand to every rank's comm_init_rccl."""

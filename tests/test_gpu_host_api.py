@@ -318,3 +318,39 @@ def test_golden_vectors_on_gpu():
         action = planner.compute_action(**kw)
         tol = 1e-7 if kind == "near" else 1e-9
         assert np.abs(action - g["action"][i]).max() < tol * max(1.0, np.abs(g["action"][i]).max()), kind
+
+
+def test_host_buffer_entry_points_equal_the_device_ones():
+    """mrf_*_host (numpy in, numpy out, one packed copy each way inside the library) against the device-tensor entry
+    points on the same inputs: identical kernels, so bit-identical results; f32 handles convert while packing."""
+    import torch
+    from multi_robot_fabrics_amd.runtime import FabricHandle
+    for scalar, exact in ((abi.F64, True), (abi.F32, False)):
+        cfg = config.panda_config(n_robots=3, horizon=4, scalar=scalar)
+        cfg.goal_estimate_mask = 0b110
+        b = scenarios.panda_batch(cfg, 5, seed=9)
+        h = FabricHandle(cfg, 0)
+        q, qd, prm = (h.tensor(b[k]) for k in ("q", "qdot", "params"))
+        sx, sv, sa = h.fk_spheres(q, qd)
+        ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, b, sx, sv, sa)
+        same = (lambda a, t: np.array_equal(a, t.double().cpu().numpy())) if exact else \
+               (lambda a, t: np.allclose(a, t.double().cpu().numpy(), rtol=1e-6, atol=1e-7))
+        hx, hv, ha = h.fk_spheres_host(b["q"], b["qdot"])
+        assert same(hx, sx) and same(hv, sv) and same(ha, sa)
+        n = lambda t: t.double().cpu().numpy()
+        act, qdd = h.compute_action(q, qd, prm, ox, ov, oa, orad, want_qddot=True)
+        hact, hqdd = h.compute_action_host(b["q"], b["qdot"], b["params"], n(ox), n(ov), n(oa), n(orad), want_qddot=True)
+        assert same(hact, act) and same(hqdd, qdd)
+        assert same(h.compute_action_host(b["q"], b["qdot"], b["params"]), h.compute_action(q, qd, prm))   # no obstacles
+        avg, tq, tqd = h.rollout(q, qd, prm, want_traj=True)
+        havg, htq, htqd = h.rollout_host(b["q"], b["qdot"], b["params"], want_traj=True)
+        assert same(havg, avg) and same(htq, tq) and same(htqd, tqd)
+        assert same(h.rollout_host(b["q"], b["qdot"], b["params"]), avg)
+        cavg, ctq, ctqd = h.rollout_cartesian(q, qd, prm, ox, ov, oa, orad, want_traj=True)
+        hcavg, hctq, hctqd = h.rollout_cartesian_host(b["q"], b["qdot"], b["params"], n(ox), n(ov), n(oa), n(orad), want_traj=True)
+        assert same(hcavg, cavg) and same(hctq, ctq) and same(hctqd, ctqd)
+        # growing staging buffers: a larger call after a small one
+        b2 = scenarios.panda_batch(cfg, 300, seed=10)
+        q2, qd2, prm2 = (h.tensor(b2[k]) for k in ("q", "qdot", "params"))
+        assert same(h.rollout_host(b2["q"], b2["qdot"], b2["params"]), h.rollout(q2, qd2, prm2))
+        torch.cuda.synchronize()

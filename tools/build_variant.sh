@@ -25,5 +25,9 @@ if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_comm.hip" ]; then
   $hip ${KERNEL_FLAGS--ffast-math} -c -o $tmp/m.o "$src/multi-robot-fabrics_amd/csrc/mrf_comm.hip" &
   objs="$objs $tmp/m.o"
 fi
+if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_hostpath.hip" ]; then
+  $hip -c -o $tmp/h.o "$src/multi-robot-fabrics_amd/csrc/mrf_hostpath.hip" &
+  objs="$objs $tmp/h.o"
+fi
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/lib$name.so $objs -ldl
