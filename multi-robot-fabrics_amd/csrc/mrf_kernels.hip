@@ -25,6 +25,18 @@
 
 namespace mrf {
 
+// -DMRF_COOP_CLOCKS: the cooperative kernel stamps s_memtime at its phase boundaries (block 0, lane 0, horizon step 5)
+// into mrf_dbg_clocks, read back by mrf_debug_clocks() -- a development aid (tools/coop_phases.py), not built by default.
+#ifdef MRF_COOP_CLOCKS
+__device__ long long mrf_dbg_clocks[32];
+#define MRF_STAMP(slot)                                                                      \
+  do {                                                                                       \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && k == 5) mrf_dbg_clocks[slot] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define MRF_STAMP(slot)
+#endif
+
 // The thread-per-row kernels whose obstacle loop streams from HBM / L2 can be built for two waves per SIMD
 // (<= 256 registers, two-phase walk) so that one wave's loads overlap the other's arithmetic: experiment switches
 // -DMRF_OCC2_ACTION / _CART / _STEP (tools/build_variant.sh), measured by tools/prof_kernels.py.
@@ -558,6 +570,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   const int N = cfg.n_robots;
   const int m01 = LO ? cfg.lo_merge01 : 0, m45 = LO ? cfg.lo_merge45 : 0;
   const int S = LO ? 8 - m01 - m45 : cfg.n_spheres;  // distinct spheres per robot (coincident link origins merged)
+  T* prm_lds = sph + (size_t)N * S * 9;              // [MRF_NPARAM][N] the scenario's parameters, read once
   const int C = coop_chunks(N);
   const int LPR = 5 * C;  // lanes per robot
   const int lane = threadIdx.x;
@@ -578,7 +591,14 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   PandaState<T> R;
   load_state(rows, row, q0, qd0, R);
   const T* mount_own = cfg.mount[i];
-  PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
+  // one scenario is a chain of dependent latencies: the 29 parameters per robot are fetched once into LDS instead of
+  // being re-read from global memory where they are used in every horizon step
+  for (int idx = lane; idx < MRF_NPARAM * N; idx += 64) {
+    const int cpar = idx / N, rr = idx - cpar * N;
+    prm_lds[idx] = prm[(int64_t)cpar * rows + scen * N + rr];
+  }
+  __syncthreads();
+  PrmView<T> P{prm_lds, N, i, {T(0), T(0), T(0)}, false};
   if (COOP_ROLLOUT && ((cfg.goal_mask >> i) & 1)) {
     PandaKin<T> K0;
     panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K0);
@@ -592,6 +612,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   const int H = COOP_ROLLOUT ? cfg.horizon : 1;
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
+    MRF_STAMP(0);
     if (COOP_ROLLOUT) {
       T dq[7];
       bool small = true;
@@ -616,8 +637,10 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
         for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
       }
     }
+    MRF_STAMP(1);
     PandaKin<T> K;
     panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
+    MRF_STAMP(2);
     __syncthreads();  // the previous step's readers are done with sph / xch
     if (LO) {
       if (writer) {
@@ -663,6 +686,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     }
     __syncthreads();
 
+    MRF_STAMP(3);
     // ---- my ego point against my chunk of the other robots' spheres
     EgoPts<T, 1> E1;
 #pragma unroll
@@ -692,6 +716,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
       T con[4] = {P[MRF_P_CONSTRAINT_0], P[MRF_P_CONSTRAINT_0 + 1], P[MRF_P_CONSTRAINT_0 + 2], P[MRF_P_CONSTRAINT_0 + 3]};
       accumulate_plane<typename LS::Plane>(cfg, E1, con, a1);
     }
+    MRF_STAMP(4);
     // ---- sum the chunk partials, then give every lane of the robot all 5 points
     for (int off = 1; off < C; off <<= 1) {
 #pragma unroll
@@ -699,19 +724,27 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
 #pragma unroll
       for (int e = 0; e < 3; ++e) a1.b[0][e] += __shfl_xor(a1.b[0][e], off);
     }
-    EgoAcc<T, NG> acc;
-#pragma unroll
-    for (int gg = 0; gg < NG; ++gg) {
-      const int srcl = i * LPR + gg * C;
-#pragma unroll
-      for (int e = 0; e < 6; ++e) acc.A[gg][e] = __shfl(a1.A[0][e], srcl);
-#pragma unroll
-      for (int e = 0; e < 3; ++e) acc.b[gg][e] = __shfl(a1.b[0][e], srcl);
-    }
-    EgoPts<T, NG> E;
-    panda_ego_points<LS::Collision::generic>(cfg, K, P, E);
+    MRF_STAMP(5);
     T qdd[7], act[7];
-    panda_finish_row<LS, true>(cfg, R, P, K, E, acc, qdd, act);
+    {
+      // Every lane of a robot finishes the solve redundantly.  Sharing the finish between the lanes of a robot (seven
+      // lanes pulling one job each with the same code, limit leaves one per lane, entry-wise sums through LDS, the
+      // two LDL^T solves side by side) was built and measured in r02: correct, but 319 us instead of 310 us per H=30
+      // rollout -- the selects that make the jobs uniform and the LDS round trips cost what the saved arithmetic gains.
+      EgoAcc<T, NG> acc;
+#pragma unroll
+      for (int gg = 0; gg < NG; ++gg) {
+        const int srcl = i * LPR + gg * C;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) acc.A[gg][e] = __shfl(a1.A[0][e], srcl);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) acc.b[gg][e] = __shfl(a1.b[0][e], srcl);
+      }
+      EgoPts<T, NG> E;
+      panda_ego_points<LS::Collision::generic>(cfg, K, P, E);
+      panda_finish_row<LS, true>(cfg, R, P, K, E, acc, qdd, act);
+    }
+    MRF_STAMP(6);
     if (COOP_ROLLOUT) {
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
@@ -1105,7 +1138,7 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
-    const size_t lds = sizeof(T) * (21 * 64 + (size_t)h->cfg.n_robots * S * 9);
+    const size_t lds = sizeof(T) * (21 * 64 + (size_t)h->cfg.n_robots * (S * 9 + MRF_NPARAM));
     dim3 block(64), grid((unsigned)n_scen);
     auto k = lo ? mrf::k_coop_panda<T, LS, true, ROLLOUT> : mrf::k_coop_panda<T, LS, false, ROLLOUT>;
     hipLaunchKernelGGL(k, grid, block, lds, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q, (const T*)qd,
@@ -1119,6 +1152,12 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
 extern "C" {
 
 int mrf_abi_version(void) { return MRF_ABI_VERSION; }
+
+#ifdef MRF_COOP_CLOCKS
+int mrf_debug_clocks(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mrf::mrf_dbg_clocks), sizeof(long long) * (n < 32 ? n : 32)) == hipSuccess ? 0 : -1;
+}
+#endif
 int64_t mrf_config_sizeof(void) { return (int64_t)sizeof(mrf_config); }
 
 void mrf_default_config_panda(mrf_config* c, int32_t n_robots, int32_t horizon) {
