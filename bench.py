@@ -173,7 +173,8 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     a.steps, a.warmup = max(1, min(args.steps, 10)), 1
     if world > 1:       # the ranks of a robot group work on the same scenarios: one batch per replica, made once
         batch = ShardedRollout.replica_batch(cfg_roll, args.scenarios, rank, world)
-    for transport in ("rccl", "peer"):
+    # two ranks sharing one GPU (the test hook) cannot form an RCCL communicator: only the peer transport runs there
+    for transport in (("peer",) if os.environ.get("MRF_BENCH_SHARE_GPU") == "1" else ("rccl", "peer")):
         a.transport = transport
         try:
             r = ShardedRollout.bench(cfg_roll, batch, a, rank, world, local_rank)
@@ -318,7 +319,7 @@ def main():
     assert torch.isfinite(avg).all() and torch.isfinite(act).all()
 
     sharded_block = None
-    if not args.no_robot_shard and not share_gpu:
+    if not args.no_robot_shard:
         args.scenarios = B
         sharded_block = robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank)
 

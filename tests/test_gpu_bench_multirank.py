@@ -46,6 +46,12 @@ def test_bare_launch_spawns_its_own_ranks():
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["scenarios_per_gpu"] == 2016
+    # the secondary block of a default run at world > 1: robots of a scenario spread over the two ranks (2 + 1), one
+    # scenario batch per replica, the exchange inside the library (peer transport here: the ranks share the GPU)
+    peer = r["robot_sharded"]["peer"]
+    assert "error" not in peer, peer
+    assert peer["config"]["robot_group_ranks"] == 2 and peer["config"]["robots_per_rank"] == [2, 1]
+    assert peer["parity_vs_fused_kernel"]["ok"] and peer["roofline"]["bound"] == "xgmi_link"
 
 
 def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
