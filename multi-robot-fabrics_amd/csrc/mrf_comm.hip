@@ -48,6 +48,17 @@ __device__ __forceinline__ T* peer_x(const PeerView& V, int dst, int gen, int n_
   return reinterpret_cast<T*>(V.base[dst] + V.off_x) + (size_t)gen * n_robots * SX * 9 * V.b_max;
 }
 
+// Payload stores into an exchange buffer.  The buffer of another rank is an IPC mapping whose caching attributes on
+// the writer's side are the driver's choice, so those stores are made at system scope (write-through to the owner's
+// memory) instead of relying on the mapping being fine-grained; the own buffer takes plain stores.
+template <typename T>
+__device__ __forceinline__ void xstore(T* p, T v, bool remote) {
+  if (remote)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else
+    *p = v;
+}
+
 template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict__ cfgp, PeerView V, int64_t n_scen,
                                                       T* __restrict__ q_io, T* __restrict__ qd_io,
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
           // ---- publish: this robot's spheres of step k into every rank's buffer (FPJ:211-225 across GPUs)
           if (active) {
             for (int g = 0; g < V.G; ++g) {
+              const bool remote = g != V.grank;
               T* dst = peer_x<T>(V, g, gen, N, SX) + ((size_t)me * SX * 9) * V.b_max + scen;
               if constexpr (LO) {
 #pragma unroll
@@ -171,9 +183,9 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
                   T* d9 = dst + ((size_t)lo_slot(sp, m01, m45) * 9) * V.b_max;
 #pragma unroll
                   for (int c = 0; c < 3; ++c) {
-                    d9[(size_t)c * V.b_max] = sp < 7 ? K1.o[sp < 7 ? sp : 0][c] : K1.p8[c];
-                    d9[(size_t)(3 + c) * V.b_max] = sp < 7 ? K1.vo[sp < 7 ? sp : 0][c] : K1.v8[c];
-                    d9[(size_t)(6 + c) * V.b_max] = cfg.jsign * (sp < 7 ? K1.ao[sp < 7 ? sp : 0][c] : K1.a8[c]);
+                    xstore(d9 + (size_t)c * V.b_max, sp < 7 ? K1.o[sp < 7 ? sp : 0][c] : K1.p8[c], remote);
+                    xstore(d9 + (size_t)(3 + c) * V.b_max, sp < 7 ? K1.vo[sp < 7 ? sp : 0][c] : K1.v8[c], remote);
+                    xstore(d9 + (size_t)(6 + c) * V.b_max, cfg.jsign * (sp < 7 ? K1.ao[sp < 7 ? sp : 0][c] : K1.a8[c]), remote);
                   }
                 }
               } else {
@@ -188,9 +200,9 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
                       T* d9 = dst + ((size_t)s * 9) * V.b_max;
 #pragma unroll
                       for (int c = 0; c < 3; ++c) {
-                        d9[(size_t)c * V.b_max] = x[c];
-                        d9[(size_t)(3 + c) * V.b_max] = v[c];
-                        d9[(size_t)(6 + c) * V.b_max] = cfg.jsign * a[c];
+                        xstore(d9 + (size_t)c * V.b_max, x[c], remote);
+                        xstore(d9 + (size_t)(3 + c) * V.b_max, v[c], remote);
+                        xstore(d9 + (size_t)(6 + c) * V.b_max, cfg.jsign * a[c], remote);
                       }
                     });
               }
