@@ -157,6 +157,14 @@ int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scenarios, const void* q
 int mrf_rollout(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* qdot0, const void* params,
                 void* avg_vel_out, void* traj_q, void* traj_qdot, void* stream);
 
+/* Replaces ForwardFabricsPlanner.rollouts_numerical_obstacles (FPJ:425-512; the per-step obstacle outputs of the
+ * rollout graph, FPJ:211-225,283-289): the sphere states every robot PUBLISHES at each horizon step of a rollout whose
+ * trajectories traj_q / traj_qd [H][dof][rows] mrf_rollout has written -- positions after the step's position update,
+ * v = J qdot and a = jdot_sign * Jdot qdot with the velocities that ENTER the step (qdot0 for step 0, traj_qd[k-1]
+ * after).  x_out, v_out, a_out [H][S][3][rows] (v_out / a_out may be NULL); one mrf_fk_spheres launch per step. */
+int mrf_rollout_sphere_traj(mrf_handle* h, int64_t n_scenarios, const void* qdot0, const void* traj_q, const void* traj_qd,
+                            void* x_out, void* v_out, void* a_out, void* stream);
+
 /* Replaces FabricsRollouts.get_velocity_rollouts / rollouts_numerical (FPC:347-489,538-563):
  * per-row independent rollout, action-then-step, obstacles at constant Cartesian velocity. */
 int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,

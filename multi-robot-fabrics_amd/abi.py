@@ -77,7 +77,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
 EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
     "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
-    "mrf_fk_spheres", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
+    "mrf_fk_spheres", "mrf_rollout_sphere_traj", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
     "mrf_compute_action_host", "mrf_rollout_host", "mrf_rollout_cartesian_host", "mrf_fk_spheres_host",
@@ -163,6 +163,8 @@ def load_library(path=None):
     lib.mrf_rollout_cartesian.restype = C.c_int
     lib.mrf_fk_spheres.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.mrf_fk_spheres.restype = C.c_int
+    lib.mrf_rollout_sphere_traj.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.mrf_rollout_sphere_traj.restype = C.c_int
     lib.mrf_exchange_spheres.argtypes = [vp]
     lib.mrf_exchange_spheres.restype = i32
     lib.mrf_step_prepare.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp]

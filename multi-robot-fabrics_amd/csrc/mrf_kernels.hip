@@ -1388,6 +1388,26 @@ int mrf_fk_spheres(mrf_handle* h, int64_t rows, const void* q, const void* qdot,
   });
 }
 
+int mrf_rollout_sphere_traj(mrf_handle* h, int64_t n_scen, const void* qdot0, const void* traj_q, const void* traj_qd,
+                            void* x_out, void* v_out, void* a_out, void* stream) {
+  MRF_CHECK_READY(h);
+  if (h->cfg.model != MRF_MODEL_PANDA7) return fail(h, MRF_E_CONFIG, "rollouts are defined for the panda7 model only");
+  if (n_scen == 0) return MRF_OK;
+  if (n_scen < 0 || !qdot0 || !traj_q || !traj_qd || !x_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  const size_t sb = h->cfg.scalar == MRF_F64 ? 8 : 4;
+  const size_t rows = (size_t)n_scen * h->cfg.n_robots;
+  const size_t step_state = 7 * rows * sb, step_out = (size_t)h->cfg.n_spheres * 3 * rows * sb;
+  for (int k = 0; k < h->cfg.horizon; ++k) {
+    const char* qk = (const char*)traj_q + (size_t)k * step_state;
+    const char* qdk = k == 0 ? (const char*)qdot0 : (const char*)traj_qd + (size_t)(k - 1) * step_state;
+    char* xo = (char*)x_out + (size_t)k * step_out;
+    char* vo = v_out ? (char*)v_out + (size_t)k * step_out : nullptr;
+    char* ao = a_out ? (char*)a_out + (size_t)k * step_out : nullptr;
+    if (int rc = mrf_fk_spheres(h, (int64_t)rows, qk, qdk, xo, vo, ao, stream)) return rc;
+  }
+  return MRF_OK;
+}
+
 int32_t mrf_exchange_spheres(const mrf_handle* h) {
   if (!h) return 0;
   const mrf_config& c = h->cfg;

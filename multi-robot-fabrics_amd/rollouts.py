@@ -153,9 +153,8 @@ class ForwardFabricsPlanner:
         q, qd, prm = h.upload(*self._rows(inputs_action))
         _, tq, tqd = h.rollout(q, qd, prm, want_traj=True)                      # [H, 7, N]
         H, N, S = self.N_horizon, self.nr_robots, h.cfg.n_spheres
-        qd_before = torch.cat([qd[None], tqd[:-1]], dim=0)                       # velocities entering step k
-        flat = lambda t: t.permute(1, 0, 2).reshape(7, H * N).contiguous()       # row = k*N + robot
-        x, v, a = (t.cpu().numpy().reshape(S, 3, H, N) for t in h.fk_spheres(flat(tq), flat(qd_before)))
+        # [H, S, 3, N] -> [S, 3, H, N]: what every robot publishes at step k (mrf_rollout_sphere_traj)
+        x, v, a = (t.permute(1, 2, 0, 3).cpu().numpy() for t in h.rollout_sphere_traj(qd, tq, tqd))
         dyn = bool(h.cfg.dynamic)
         xN, vN, aN = ({"robot_%d" % i: [] for i in range(N)} for _ in range(3))
         for i in range(N):

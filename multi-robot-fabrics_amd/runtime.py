@@ -177,6 +177,19 @@ class FabricHandle:
         self._check(rc)
         return x, v, a
 
+    def rollout_sphere_traj(self, qdot0, traj_q, traj_qd, stream=None):
+        """Sphere states every robot publishes at each step of a rollout (FPJ:211-225): x, v, a each [H, S, 3, rows]."""
+        H, _, rows = traj_q.shape
+        S = self.cfg.n_spheres
+        x = torch.empty((H, S, 3, rows), dtype=self.dtype, device=self.device)
+        v, a = torch.empty_like(x), torch.empty_like(x)
+        rc = self.lib.mrf_rollout_sphere_traj(self._h, rows // self.cfg.n_robots, self._arg(qdot0, (self.dof, rows), "qdot0"),
+                                              self._arg(traj_q, (self.cfg.horizon, self.dof, rows), "traj_q"),
+                                              self._arg(traj_qd, (self.cfg.horizon, self.dof, rows), "traj_qd"),
+                                              self._arg(x), self._arg(v), self._arg(a), self._stream(stream))
+        self._check(rc)
+        return x, v, a
+
     @property
     def exchange_spheres(self):
         """Spheres per robot in the sharded exchange buffers (coincident link origins travel once)."""
