@@ -86,3 +86,15 @@ def test_two_processes_one_gpu_peer_exchange(n_robots, horizon, n_scen, table, d
     tol = 1e-9 if dtype == "f64" else 2e-3
     for r in ranks:
         assert r["err"] < tol, ranks
+
+
+def test_plain_c_consumer_two_processes_one_gpu():
+    """The same two-process peer exchange driven from plain C++ (examples/sharded_rollout_c.cpp: fork, pipes for the IPC
+    handles, mrf_comm_peer_open / _connect, mrf_rollout_sharded) -- a non-Python consumer of the ABI runs the north-star
+    partitioning; each process checks its rows against the fused kernel."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000")
+    out = subprocess.run([os.path.join(ROOT, "examples", "sharded_rollout_c"), "150", "10"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr[-2000:]
+    assert out.stdout.count("rel err vs fused kernel") == 2, out.stdout

@@ -277,3 +277,12 @@ def test_deadlock_config_defaults_and_null_handles():
     assert lib.mrf_deadlock_step(None, 4, C.byref(c), -1, None, None, None, None, None, None, None) == -1
     assert lib.mrf_apply_action(None, 4, None, None, None, vl, -1.0, None) == -1
     assert lib.mrf_episode_run(None, None, 4, 1, None, 0, vl, -1.0, *([None] * 10), 0, None) == -1
+
+
+def test_plain_c_consumer_of_the_sharded_abi_builds():
+    """examples/sharded_rollout_c.cpp drives mrf_comm_peer_* / mrf_rollout_sharded from C++ without Python or torch;
+    it must compile and link against the library as built (it RUNS in tests/test_gpu_sharded_abi.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    assert os.path.exists(os.path.join(root, "examples", "sharded_rollout_c"))
