@@ -39,3 +39,15 @@ def test_three_robot_config_without_rollouts(tmp_path):
     res = ex.define_run_panda_example(str(cfg), n_steps=25)
     assert res["config"]["n_robots"] == 3 and res["time_in_deadlock_steps"] == 0
     assert res["host_api_vs_device_episode_max_abs_dq"] < 1e-9      # static fabrics: no sphere velocities involved
+
+
+def test_pointmass_static_example_runs_collision_free():
+    """BASELINE.json configs[0]: 4 point-mass robots, static fabrics (example_pointmasses_static.py), mirrored classes."""
+    spec = importlib.util.spec_from_file_location("example_pointmasses_static",
+                                                  os.path.join(ROOT, "examples", "example_pointmasses_static.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run_point_example(n_steps=400)
+    assert all(np.isfinite(d) for d in res["distance_to_goal_m"]) and res["min_clearance_m"] > 0.0
+    start = [4.0 ** 2 + 3.75 ** 2, 4.0 ** 2 + 3.75 ** 2, 5.0 ** 2 + 1.25 ** 2, 5.0 ** 2 + 6.23 ** 2]
+    assert all(d * d < s for d, s in zip(res["distance_to_goal_m"], start))       # every robot moved towards its goal
