@@ -553,6 +553,21 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
 //   the chunk partials are summed with xor-shuffles, the 5 points gathered with indexed shuffles   [wave shuffles]
 //   and every lane of a robot finishes the 7x7 part redundantly.
 // COOP_ROLLOUT = true is the coupled rollout (FPJ:190-249), false one coupled compute_action (EXJ:394-448).
+// value of the lane whose index differs in bit 0 (X = 1) or bit 1 (X = 2) within its quad: v_mov_b32 with quad_perm
+template <int X>
+__device__ __forceinline__ int quad_xor_b32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, X == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true);  // quad_perm [1,0,3,2] / [2,3,0,1]
+}
+template <int X>
+__device__ __forceinline__ double quad_xor(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  return __hiloint2double(quad_xor_b32<X>(hi), quad_xor_b32<X>(lo));
+}
+template <int X>
+__device__ __forceinline__ float quad_xor(float v) {
+  return __int_as_float(quad_xor_b32<X>(__float_as_int(v)));
+}
+
 __host__ __device__ inline int coop_chunks(int n_robots) {
   return 5 * n_robots * 4 <= 64 ? 4 : (5 * n_robots * 2 <= 64 ? 2 : 1);
 }
@@ -608,6 +623,25 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   }
   const bool dyn = cfg.dynamic != 0;
   const bool acc_on = dyn && (COOP_ROLLOUT || use_accel);
+  // The (other robot, sphere) pairs this lane folds are the same in every horizon step: their LDS offsets, radii and
+  // multiplicities are worked out once (an integer division and a load from the constants per pair otherwise sit on
+  // the single wave's critical path in every step).  Up to COOP_PRE pairs per lane; larger chunks use the loop.
+  constexpr int COOP_PRE = 4;
+  const int M_all = (N - 1) * S;
+  const bool pre = (M_all + C - 1) / C <= COOP_PRE;
+  int pre_off[COOP_PRE];
+  T pre_rad[COOP_PRE], pre_mul[COOP_PRE];
+#pragma unroll
+  for (int t = 0; t < COOP_PRE; ++t) {
+    const int m = c + t * C;
+    const bool valid = pre && m < M_all;
+    const int d = valid ? m / S : 0, sp = valid ? m - d * S : 0;
+    int jr = i + 1 + d;
+    if (jr >= N) jr -= N;
+    pre_off[t] = valid ? (jr * S + sp) * 9 : -1;
+    pre_rad[t] = cfg.sphere_r[LO ? lo_sphere(sp, m01, m45) : sp];
+    pre_mul[t] = LO ? T(lo_count(sp, m01, m45)) : T(1);
+  }
   T sumsq = T(0);
   const int H = COOP_ROLLOUT ? cfg.horizon : 1;
 #pragma unroll 1
@@ -697,7 +731,15 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     ego_point_links<LS::Collision::generic>(cfg, P, g, E1.rb[0][0], E1.rb[0][1], E1.nl[0]);
     EgoAcc<T, 1> a1;
     a1.zero();
-    if (cfg.n_ego > 0) {
+    if (cfg.n_ego > 0 && pre) {
+#pragma unroll
+      for (int t = 0; t < COOP_PRE; ++t) {
+        if (pre_off[t] < 0) continue;
+        const T* src = sph + pre_off[t];
+        T x[3] = {src[0], src[1], src[2]}, v[3] = {src[3], src[4], src[5]}, a[3] = {src[6], src[7], src[8]};
+        accumulate_obstacle<typename LS::Collision>(cfg, E1, x, v, a, pre_rad[t], false, a1, pre_mul[t]);
+      }
+    } else if (cfg.n_ego > 0) {
       const int M = (N - 1) * S;
 #pragma unroll 1
       for (int m = c; m < M; m += C) {
@@ -718,11 +760,18 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     }
     MRF_STAMP(4);
     // ---- sum the chunk partials, then give every lane of the robot all 5 points
-    for (int off = 1; off < C; off <<= 1) {
+    // the C (<= 4) chunk lanes of a point are neighbours inside a quad: quad-permute DPP moves, no LDS crossbar
+    if (C >= 2) {
 #pragma unroll
-      for (int e = 0; e < 6; ++e) a1.A[0][e] += __shfl_xor(a1.A[0][e], off);
+      for (int e = 0; e < 6; ++e) a1.A[0][e] += quad_xor<1>(a1.A[0][e]);
 #pragma unroll
-      for (int e = 0; e < 3; ++e) a1.b[0][e] += __shfl_xor(a1.b[0][e], off);
+      for (int e = 0; e < 3; ++e) a1.b[0][e] += quad_xor<1>(a1.b[0][e]);
+    }
+    if (C >= 4) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) a1.A[0][e] += quad_xor<2>(a1.A[0][e]);
+#pragma unroll
+      for (int e = 0; e < 3; ++e) a1.b[0][e] += quad_xor<2>(a1.b[0][e]);
     }
     MRF_STAMP(5);
     T qdd[7], act[7];
