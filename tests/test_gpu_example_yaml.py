@@ -51,3 +51,21 @@ def test_pointmass_static_example_runs_collision_free():
     assert all(np.isfinite(d) for d in res["distance_to_goal_m"]) and res["min_clearance_m"] > 0.0
     start = [4.0 ** 2 + 3.75 ** 2, 4.0 ** 2 + 3.75 ** 2, 5.0 ** 2 + 1.25 ** 2, 5.0 ** 2 + 6.23 ** 2]
     assert all(d * d < s for d, s in zip(res["distance_to_goal_m"], start))       # every robot moved towards its goal
+
+
+def test_evaluate_horizon_protocol(tmp_path):
+    """examples/evaluation/evaluate_horizon.py: the reference's benchmark script (K = 1, 10, 20) on the mirrored classes;
+    writes the pickle in the reference's format."""
+    import pickle
+    spec = importlib.util.spec_from_file_location("evaluate_horizon",
+                                                  os.path.join(ROOT, "examples", "evaluation", "evaluate_horizon.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    horizons, data = mod.define_run_evaluations(n_steps=12)
+    assert horizons == [1, 10, 20] and [d.shape for d in data] == [(1, 12)] * 3
+    assert all(np.isfinite(d).all() and (d > 0).all() for d in data)
+    with open(tmp_path / "results_horizon", "wb") as fp:
+        pickle.dump(data, fp)
+    ref = pickle.load(open("/root/reference/evaluation/results_horizon", "rb")) if os.path.exists("/root/reference/evaluation/results_horizon") else None
+    if ref is not None:       # same container type and array rank as the reference's own pickle (build container only)
+        assert type(ref) is type(data) and len(ref) == len(data) and ref[0].ndim == data[0].ndim
