@@ -235,7 +235,9 @@ int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int
  *                        flag there and polls the peers' flags for the same scenarios (bounded spin: a peer that never
  *                        arrives ends the kernel and is reported by mrf_comm_status, it cannot hang the GPU).
  *
- * Every rank of the group must make the same sequence of mrf_rollout_sharded calls with the same n_scen.
+ * world <= n_robots; further GPUs run replicas of the group on other scenario batches (independent, no exchange).
+ * Every rank of the group must make the same sequence of mrf_rollout_sharded calls with the same n_scen.  A timed-out
+ * peer exchange is sticky: every later wait of that communicator ends at once, until it is destroyed.
  *   q_io, qdot_io [dof][n_scen*count]  the OWNED rows, row = scenario*count + (robot - first); advanced in place
  *   params        [MRF_NPARAM][n_scen*count]      avg_vel_out [n_scen*count]
  */
