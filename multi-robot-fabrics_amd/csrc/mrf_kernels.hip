@@ -114,7 +114,11 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
           xo[c] = buf[c] + tk * vo[c];  // Cartesian rollout: x += dt*v per step (FPC:448-453); tk = 0 otherwise
           ao[c] = has_a ? buf[6 + c] : T(0);
         }
+#ifdef MRF_OBST_NOFOLD  // development switch (tools/build_variant.sh): the obstacle stream alone, results meaningless
+        acc.b[0][0] += xo[0] + xo[1] + xo[2] + vo[0] + vo[1] + vo[2] + ao[0] + ao[1] + ao[2] + buf[9];
+#else
         accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[9], allow_planar && !is_static && cfg.obst_dim == 2, acc);
+#endif
       });
 #endif
 }
