@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""The reference's examples/example_pointmasses_dynamic.py through the mirrored classes: four point-mass robots, six
+static scene spheres and -- unlike the static twin -- the other three robots as DYNAMIC obstacles of dimension 2
+(set_planner_point :101-130: number_dynamic_obstacles = n_robots - 1, dynamic_obstacle_dimension = 2), passed with the
+reference's per-index keyword names x_obst_dynamic_j / xdot_obst_dynamic_j / xddot_obst_dynamic_j /
+radius_obst_dynamic_j (run_point_example :183-212; accelerations zero: "no dependence on fabrics of others").
+The gym simulator is replaced by arithmetic (acceleration-controlled point masses, dt = 0.01), as in
+example_pointmasses_static.py, whose remarks on creeping contact apply here too.
+
+usage: python examples/example_pointmasses_dynamic.py [--steps 1500]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+from multi_robot_fabrics_amd.goals import GoalComposition
+from multi_robot_fabrics_amd.kinematics import GenericURDFFk
+from multi_robot_fabrics_amd.planner import ParameterizedFabricPlanner
+
+
+def set_planner_point(goal, n_obstacles=2, n_dyn_obstacles=0):
+    """:101-130."""
+    fk = GenericURDFFk(None, "world", "base_link")
+    planner = ParameterizedFabricPlanner(
+        3, fk,
+        collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
+        collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
+    planner.set_components(["base_link"], {}, goal=goal, number_obstacles=n_obstacles,
+                           number_dynamic_obstacles=n_dyn_obstacles, dynamic_obstacle_dimension=2)
+    planner.concretize()
+    return planner
+
+
+def run_point_example(n_steps=1500):
+    obstacles_pos = [[1, 1.25, 0], [1, 3.75, 0], [1, -1.25, 0], [-1.1, 0, 0], [-1.1, 2.5, 0], [-1.1, -2.5, 0]]    # :145
+    obstacles_radius = [1, 1, 1, 1, 1, 1]
+    robots_pos = np.array([[-2.5, 0.01, 0.0], [-2.5, -2.49, 0.0], [2.5, 1.26, 0.0], [2.5, 3.74, 0.0]])             # :149
+    goal_robots = [np.array([1.5, 3.76]), np.array([1.5, 1.26]), np.array([-2.5, 0.01]), np.array([-2.5, -2.49])]
+    r_robots = [np.array(0.2)] * 4
+    n_robots = 4
+    goal = GoalComposition(name="goal", content_dict={
+        "subgoal0": {"weight": 1, "is_primary_goal": True, "indices": [0, 1], "parent_link": "world",
+                     "child_link": "base_link", "desired_position": [1.5, 0.99], "epsilon": 0.1, "type": "staticSubGoal"}})
+    planner_point = set_planner_point(goal, n_obstacles=len(obstacles_pos), n_dyn_obstacles=n_robots - 1)
+    q = robots_pos.copy()
+    qdot = np.zeros_like(q)
+    dt = 0.01
+    min_clear, first_contact = np.inf, None
+    pos_obs = [np.array(p, dtype=float) for p in obstacles_pos]
+    for step in range(n_steps):
+        action = np.zeros((n_robots, 3))
+        for i in range(n_robots):                                                                                  # :176-212
+            others = [j for j in range(n_robots) if j != i]
+            dyn = {}
+            for k, j in enumerate(others):
+                dyn["x_obst_dynamic_%d" % k] = q[j, 0:2]
+                dyn["xdot_obst_dynamic_%d" % k] = qdot[j, 0:2]
+                dyn["xddot_obst_dynamic_%d" % k] = np.array([0.0, 0.0])
+                dyn["radius_obst_dynamic_%d" % k] = r_robots[j]
+            action[i] = planner_point.compute_action(q=q[i], qdot=qdot[i], x_goal_0=goal_robots[i],
+                                                     weight_goal_0=goal.sub_goals()[0].weight(), x_obsts=pos_obs,
+                                                     radius_obsts=obstacles_radius, radius_body_base_link=r_robots[i], **dyn)
+        qdot = qdot + dt * action
+        q = q + dt * qdot
+        for i in range(n_robots):
+            for j in range(i + 1, n_robots):
+                min_clear = min(min_clear, float(np.linalg.norm(q[i, :2] - q[j, :2]) - 0.4))
+            for p, r in zip(obstacles_pos, obstacles_radius):
+                min_clear = min(min_clear, float(np.linalg.norm(q[i, :2] - np.array(p[:2])) - r - 0.2))
+        if first_contact is None and min_clear < 0.0:
+            first_contact = step
+    dist = [float(np.linalg.norm(q[i, :2] - goal_robots[i])) for i in range(n_robots)]
+    return {"steps": n_steps, "distance_to_goal_m": dist, "min_clearance_m": min_clear, "first_contact_step": first_contact,
+            "final_speed": [float(np.linalg.norm(v)) for v in qdot]}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=1500)
+    print(json.dumps(run_point_example(ap.parse_args().steps), indent=1))

@@ -84,3 +84,30 @@ def test_random_pick_and_place_evaluation_on_device():
     res = mod.run_case("rollouts dynamic", params, B=24, steps=3000, n_blocks=1, seed=3)
     assert res["all_finite"] and res["collision_episodes"] == 0
     assert res["success_rate"] >= 0.75, res          # the arms do pick their block and bring it home
+
+
+def _load(name, *parts):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", *parts))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_cartesian_example_completes_pick_and_place():
+    """examples/example_pandas_cartesian.py: the reference's Cartesian driver (EXC:124-520) through the mirrored classes --
+    per-robot FabricsRollouts, compute_x_obsts_dyn_0, deadlock_checking, main / grasp planner by state, the host state
+    machine -- one block per robot, until both robots report state 10."""
+    mod = _load("example_pandas_cartesian", "example_pandas_cartesian.py")
+    res = mod.define_run_panda_example(n_robots=2, n_steps=2500, horizon=5, n_cubes=2)
+    assert res["success"] == [True, True] and res["blocks_picked"] == [1, 1]
+    assert all({1, 2, 3, 12, 4, 5, 10} <= set(s) for s in res["states_visited"])
+    assert res["min_clearance_m"] > 0.0 and np.isfinite(res["solver_time_ms_mean"])
+
+
+def test_pointmass_dynamic_example():
+    """examples/example_pointmasses_dynamic.py: per-index dynamic-obstacle keywords (x_obst_dynamic_j ...), dimension 2."""
+    mod = _load("example_pointmasses_dynamic", "example_pointmasses_dynamic.py")
+    res = mod.run_point_example(n_steps=300)
+    assert all(np.isfinite(d) for d in res["distance_to_goal_m"]) and res["min_clearance_m"] > 0.0
+    start = [4.0 ** 2 + 3.75 ** 2, 4.0 ** 2 + 3.75 ** 2, 5.0 ** 2 + 1.25 ** 2, 5.0 ** 2 + 6.23 ** 2]
+    assert all(d * d < s for d, s in zip(res["distance_to_goal_m"], start))
