@@ -71,10 +71,11 @@ template <class CL, typename T>
 __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int64_t rows, int64_t r, int n_obst,
                                                       int n_static, const T* __restrict__ ox, const T* __restrict__ ov,
                                                       const T* __restrict__ oa, const T* __restrict__ orad, T tk,
-                                                      bool allow_planar, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+                                                      bool allow_planar, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc,
+                                                      int m_first = 0) {  // obstacles [m_first, n_obst)
 #ifdef MRF_NO_ARRAY_PREFETCH
 #pragma unroll 1
-  for (int m = 0; m < n_obst; ++m) {
+  for (int m = m_first; m < n_obst; ++m) {
     const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
     T xo[3], vo[3], ao[3];
 #pragma unroll
@@ -93,8 +94,9 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
   const T* pv = ov ? ov : ox;
   const T* pa = oa ? oa : ox;
   pipelined_pairs<T, 10>(
-      n_obst,
-      [&](int m, T (&buf)[10]) {
+      n_obst - m_first,
+      [&](int mi, T (&buf)[10]) {
+        const int m = mi + m_first;
         const int64_t base = (int64_t)(m * 3) * rows + r;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -104,7 +106,8 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
         }
         buf[9] = orad[(int64_t)m * rows + r];
       },
-      [&](int m, T (&buf)[10]) {
+      [&](int mi, T (&buf)[10]) {
+        const int m = mi + m_first;
         const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
         const bool has_v = ov && !is_static, has_a = oa && !is_static;
         T xo[3], vo[3], ao[3];
@@ -121,6 +124,59 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
 #endif
       });
 #endif
+}
+
+// The Cartesian rollout passes over the same obstacle set H times (x0, v, a, r are constants of the rollout; only the
+// elapsed time changes, FPC:448-453).  The set does not fit on chip (16 obstacles = 82 KB per wave in f64), but a prefix
+// does: the first CART_RESIDENT<T> obstacles of every row are copied once into a per-wave LDS tile [m][10][64] and folded
+// from there in every step, the rest streams from HBM / the Infinity Cache as before.
+template <typename T>
+constexpr int CART_RESIDENT = 35840 / (640 * (int)sizeof(T));  // 7 (f64), 14 (f32): 35 KB, four waves per CU
+
+template <typename T>
+__device__ __forceinline__ void stage_resident_obstacles(T* __restrict__ res, int lane, int nres, int64_t rows, int64_t r,
+                                                         const T* __restrict__ ox, const T* __restrict__ ov,
+                                                         const T* __restrict__ oa, const T* __restrict__ orad) {
+  const T* pv = ov ? ov : ox;  // missing arrays: any finite value, zeroed in the fold
+  const T* pa = oa ? oa : ox;
+#pragma unroll 1
+  for (int m = 0; m < nres; ++m) {
+    const int64_t base = (int64_t)(m * 3) * rows + r;
+    T* dst = res + m * 640 + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dst[c * 64] = ox[base + c * rows];
+      dst[(3 + c) * 64] = pv[base + c * rows];
+      dst[(6 + c) * 64] = pa[base + c * rows];
+    }
+    dst[9 * 64] = orad[(int64_t)m * rows + r];
+  }
+}
+
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_resident(const DevCfg<T>& cfg, const T* __restrict__ res, int lane, int nres,
+                                                   int n_static, bool any_v, bool any_a, T tk, const EgoPts<T, NG>& E,
+                                                   EgoAcc<T, NG>& acc) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  pipelined_pairs<T, 10>(
+      nres,
+      [&](int m, T (&buf)[10]) {
+        lds_ptr src = (lds_ptr)(res + m * 640 + lane);
+#pragma unroll
+        for (int c = 0; c < 10; ++c) buf[c] = src[c * 64];
+      },
+      [&](int m, T (&buf)[10]) {
+        const bool is_static = m < n_static;
+        const bool has_v = any_v && !is_static, has_a = any_a && !is_static;
+        T xo[3], vo[3], ao[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vo[c] = has_v ? buf[3 + c] : T(0);
+          xo[c] = buf[c] + tk * vo[c];
+          ao[c] = has_a ? buf[6 + c] : T(0);
+        }
+        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[9], false, acc);
+      });
 }
 
 // ---------------------------------------------------------------------------- compute_action
@@ -824,8 +880,10 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
 }
 
 // ---------------------------------------------------------------------------- Cartesian rollout
-template <typename T, class LS>
-__global__ __launch_bounds__(256) MRF_ATTR_CART void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+// RES: the first CART_RESIDENT<T> obstacles live in LDS for the whole rollout (one wave per block); RES = false is the
+// plain streaming form with 256-thread blocks (switch -DMRF_CART_STREAM_ONLY, A/B by tools/prof_kernels.py).
+template <typename T, class LS, bool RES>
+__global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
                                                              const T* __restrict__ prm, int n_obst, int n_static,
                                                              const T* __restrict__ ox0, const T* __restrict__ ov,
@@ -840,6 +898,9 @@ __global__ __launch_bounds__(256) MRF_ATTR_CART void k_rollout_cart_panda(const 
   load_state(rows, r, q0, qd0, R);
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   const T* mount_own = cfg.mount[(int)(r % cfg.n_robots)];
+  __shared__ T res[RES ? CART_RESIDENT<T> * 640 : 1];
+  const int nres = RES ? (n_obst < CART_RESIDENT<T> ? n_obst : CART_RESIDENT<T>) : 0;
+  if constexpr (RES) stage_resident_obstacles(res, (int)threadIdx.x, nres, rows, r, ox0, ov, oa, orad);
   T sumsq = T(0);
   T tk = T(0);  // elapsed obstacle time k*dt
   const int H = cfg.horizon;
@@ -849,7 +910,11 @@ __global__ __launch_bounds__(256) MRF_ATTR_CART void k_rollout_cart_panda(const 
     panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc);
+          if constexpr (RES)
+            obstacles_resident<typename LS::Collision>(cfg, res, (int)threadIdx.x, nres, n_static, ov != nullptr,
+                                                       oa != nullptr, tk, E, acc);
+          obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
+                                                        nres);
         },
         qdd, act);
     // system_step (FPC:77-92); cos q / sin q advance by the angle-sum formula while every |dq| of the wave is small
@@ -1419,9 +1484,16 @@ int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const voi
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
-    return launch(h, mrf::k_rollout_cart_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows,
+#ifdef MRF_CART_STREAM_ONLY
+    return launch(h, mrf::k_rollout_cart_panda<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows,
                   (const T*)q0, (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0,
                   (const T*)ov, (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+#else
+    return launch(h, mrf::k_rollout_cart_panda<T, LS, true>, dim3((unsigned)((rows + 63) / 64)), dim3(64), st,
+                  (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0, (const T*)qdot0, (const T*)params, (int)n_obst,
+                  (int)n_obst_static, (const T*)ox0, (const T*)ov, (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q,
+                  (T*)traj_qd);
+#endif
   });
 }
 
