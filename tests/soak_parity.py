@@ -2,7 +2,7 @@
 Many seeds of wide-spread scenarios -- including near-contact and penetrating sphere pairs (x < 0) -- through the
 rollout, the coupled action and the robot-sharded rollout (both transports, group of one), f64, against the oracle, over
 random robot counts, horizons, kernel selections, collision-link masks and sphere tables (link origins / offset
-spheres).  Prints the worst relative errors."""
+spheres).  Prints the worst relative errors, with a running summary every 250 seeds."""
 import os
 import sys
 
@@ -95,6 +95,8 @@ def main():
         sel = np.isfinite(want_act).all(0) & np.isfinite(act).all(0) & (rowx >= CLEAR)
         if sel.any():
             worst["action"] = max(worst["action"], float(np.abs(act[:, sel] - want_act[:, sel]).max() / np.abs(want_act[:, sel]).max()))
+        if (seed + 1) % 250 == 0:   # running summary: a run cut short by a time limit still leaves its findings behind
+            print({"seeds_done": seed + 1, "worst_rel_err": worst, "rows_with_nonfinite_results": nonfinite}, flush=True)
     print({"seeds": n_seeds, "clear_threshold_x": CLEAR, "worst_rel_err": worst, "rows_with_nonfinite_results": nonfinite})
 
 
