@@ -105,6 +105,16 @@ def main():
         y = yaml.safe_load(f)
     out["yaml_keys"] = np.array(sorted(y))
     out["yaml_values"] = np.array([float(y[k]) for k in sorted(y)])
+    # format (and summary statistics) of the reference's recorded benchmark pickle, evaluation/results_horizon: what
+    # examples/evaluation/evaluate_horizon.py has to reproduce in shape; the numbers are the ones BASELINE.md quotes
+    import pickle
+    with open(os.path.join(ref, "evaluation", "results_horizon"), "rb") as f:
+        rec = pickle.load(f)
+    out["results_horizon_container"] = np.array(type(rec).__name__)
+    out["results_horizon_shapes"] = np.array([np.asarray(r).shape for r in rec])
+    out["results_horizon_dtype"] = np.array(str(np.asarray(rec[0]).dtype))
+    out["results_horizon_mean_s"] = np.array([float(np.asarray(r).mean()) for r in rec])
+    out["results_horizon_median_s"] = np.array([float(np.median(np.asarray(r))) for r in rec])
     np.savez(os.path.join(HERE, "reference_static.npz"), **out)
     print("wrote reference_static.npz:", len(out), "arrays;", "joint order", order[:18])
 

@@ -66,9 +66,12 @@ def test_evaluate_horizon_protocol(tmp_path):
     assert all(np.isfinite(d).all() and (d > 0).all() for d in data)
     with open(tmp_path / "results_horizon", "wb") as fp:
         pickle.dump(data, fp)
-    ref = pickle.load(open("/root/reference/evaluation/results_horizon", "rb")) if os.path.exists("/root/reference/evaluation/results_horizon") else None
-    if ref is not None:       # same container type and array rank as the reference's own pickle (build container only)
-        assert type(ref) is type(data) and len(ref) == len(data) and ref[0].ndim == data[0].ndim
+    # same container type, length, array rank and dtype as the reference's own pickle (evaluation/results_horizon), whose
+    # format is recorded in the committed fixture by tests/golden/make_reference_static_golden.py
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_static.npz"))
+    assert type(data).__name__ == str(g["results_horizon_container"]) and len(data) == len(g["results_horizon_shapes"])
+    assert all(d.ndim == len(sh) and d.shape[0] == sh[0] for d, sh in zip(data, g["results_horizon_shapes"]))
+    assert all(str(d.dtype) == str(g["results_horizon_dtype"]) for d in data)
 
 
 def test_random_pick_and_place_evaluation_on_device():
