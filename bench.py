@@ -17,6 +17,7 @@ CHILD before it has touched the GPU, relays rank 0's JSON line and exits with th
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -112,6 +113,12 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
     # thread-count sweep on small samples (the box's usable cores can be fewer than it lists), then one bounded
     # sample at the best count and one on a single thread
     cands = sorted({1, 8, 16, 32, 64, 128, ncores} & set(range(1, ncores + 1)))
+    if quota:
+        # More threads than the cgroup's CPU budget cannot sustain more of this compute-bound loop; a short probe at such
+        # a count can still run ahead of the quota for a moment and win the sweep with a rate the long sample then does
+        # not reproduce (seen on the GPU box: 32 threads "1.9e4" in the probe, 1.0e4 sustained on a 16-core quota).
+        cap = max(1, int(math.ceil(quota)))
+        cands = sorted({c for c in cands if c <= cap} | {min(cap, ncores)})
     probe = {}
     for th in cands:
         oracle_lib.set_threads(th)
@@ -127,7 +134,9 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
         out[label] = dict(rate=n2 / t2, scenarios=n2, seconds=t2, threads=threads)
     best = out["best"] if out["best"]["rate"] >= out["single"]["rate"] else out["single"]
     return {
-        "value": best["rate"], "unit": "control-steps/s", "cores": best["threads"], "kind": "port",
+        "value": best["rate"], "unit": "control-steps/s",
+        "cores": int(min(best["threads"], math.ceil(quota))) if quota else best["threads"], "threads": best["threads"],
+        "kind": "port",
         "sample": f"{best['scenarios']} scenarios of the same workload, one control step each, {best['seconds']:.1f} s; "
                   f"float64 C++ restatement (oracle/mrf_oracle.cpp, -O3 -march=native, OpenMP one scenario per thread); "
                   f"thread count chosen by a sweep over {cands}",
