@@ -1,4 +1,4 @@
-"""Randomised parity soak (script, not collected by pytest): python3 tests/soak_parity.py [n_seeds]
+"""Randomised parity soak (script, not collected by pytest): python3 tests/soak_parity.py [n_seeds] [first_seed]
 Many seeds of wide-spread scenarios -- including near-contact and penetrating sphere pairs (x < 0) -- through the
 rollout, the coupled action and the robot-sharded rollout (both transports, group of one), f64, against the oracle, over
 random robot counts, horizons, kernel selections, collision-link masks and sphere tables (link origins / offset
@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def trajectory_min_barrier(oracle, config, cfg, states, B, N):
     """Smallest barrier coordinate x per scenario over a list of joint states [7, B*N] (the oracle's trajectory): ego
-    points = link origins 3..8 (r = 0.08) against the configured spheres of every other robot, and the table plane.
+    points = link origins 3..8 (r = 0.08) against the configured spheres of every other robot, the table plane, and
+    the distance of every joint to its limits (rad).
     A rollout that comes close to (or through) a barrier is chaotic -- 1/x^4 metrics, 1/x^8 forces -- and round-off of
     1e-16 grows by orders of magnitude per step there; parity is judged on the rows that stay clear."""
     lo = config.panda_config(n_robots=N, horizon=1)
@@ -34,7 +35,36 @@ def trajectory_min_barrier(oracle, config, cfg, states, B, N):
                     d = np.linalg.norm(ego[:, None, :, :, i] - sph[None, :, :, :, j], axis=2)
                     xm = np.minimum(xm, (d / (rad[None, :, None] + 0.08) - 1).reshape(-1, B).min(axis=0))
             xm = np.minimum(xm, (ego[:, 2, :, i] - config.Z_TABLE - 0.08).min(axis=0))
+        # the joint-limit leaves are barriers as well (x = q - lo, hi - q in rad): a row that runs into or through a
+        # joint limit diverges like one that runs through a sphere (r02: the three rows above 1e-9 in a 4000-seed run
+        # were all of this kind and had passed a filter that looked at spheres and the plane only)
+        lim = np.array(config.PANDA_LIMITS)
+        ql = qq.reshape(7, B, N)
+        xm = np.minimum(xm, np.minimum(ql - lim[:, 0, None, None], lim[:, 1, None, None] - ql).min(axis=(0, 2)))
     return xm
+
+
+def draw_seed(seed):
+    """The planner configuration and the batch of one soak seed (shared with tests/soak_parity_debug.py)."""
+    from multi_robot_fabrics_amd import config, scenarios
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(2, 5))
+    cfg = config.panda_config(n_robots=N, horizon=int(rng.integers(2, 9)), dynamic=int(rng.integers(0, 2)))
+    cfg.goal_estimate_mask = int(rng.integers(0, 1 << N))
+    cfg.kernel_select = int(rng.integers(0, 3))
+    if rng.random() < 0.4:
+        cfg.ego_link_mask = int(rng.integers(1, 64))
+    if rng.random() < 0.4:
+        links, offs = config.sphere_offsets_per_link(int(rng.integers(1, 4)))
+        config.set_spheres(cfg, links, offs, radii=rng.uniform(0.05, 0.09, len(links)))
+    B = int(rng.integers(1, 60))
+    lim = np.array(config.PANDA_LIMITS)
+    p0 = scenarios.pos0(N)
+    batch = scenarios.panda_batch(cfg, B, seed=seed, x_min=0.2)
+    spread = rng.choice([0.3, 0.8, 1.5])
+    q = np.clip(p0[None] + rng.uniform(-spread, spread, (B, N, 7)), lim[:, 0] + 0.05, lim[:, 1] - 0.05)
+    batch["q"] = np.ascontiguousarray(q.reshape(-1, 7).T)
+    return cfg, batch, B, N
 
 
 def main():
@@ -43,28 +73,13 @@ def main():
     from multi_robot_fabrics_amd import abi, config, scenarios
     from multi_robot_fabrics_amd.runtime import FabricHandle
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     worst = {"rollout": 0.0, "action": 0.0, "rollout_near_or_through_a_barrier": 0.0, "sharded_peer": 0.0, "sharded_rccl": 0.0}
     CLEAR = 0.05        # rows whose whole trajectory keeps every barrier coordinate above this are judged
     from multi_robot_fabrics_amd.sharded import ShardedRollout
     nonfinite = 0
-    for seed in range(n_seeds):
-        rng = np.random.default_rng(1000 + seed)
-        N = int(rng.integers(2, 5))
-        cfg = config.panda_config(n_robots=N, horizon=int(rng.integers(2, 9)), dynamic=int(rng.integers(0, 2)))
-        cfg.goal_estimate_mask = int(rng.integers(0, 1 << N))
-        cfg.kernel_select = int(rng.integers(0, 3))
-        if rng.random() < 0.4:
-            cfg.ego_link_mask = int(rng.integers(1, 64))
-        if rng.random() < 0.4:
-            links, offs = config.sphere_offsets_per_link(int(rng.integers(1, 4)))
-            config.set_spheres(cfg, links, offs, radii=rng.uniform(0.05, 0.09, len(links)))
-        B = int(rng.integers(1, 60))
-        lim = np.array(config.PANDA_LIMITS)
-        p0 = scenarios.pos0(N)
-        batch = scenarios.panda_batch(cfg, B, seed=seed, x_min=0.2)
-        spread = rng.choice([0.3, 0.8, 1.5])
-        q = np.clip(p0[None] + rng.uniform(-spread, spread, (B, N, 7)), lim[:, 0] + 0.05, lim[:, 1] - 0.05)
-        batch["q"] = np.ascontiguousarray(q.reshape(-1, 7).T)
+    for seed in range(first_seed, first_seed + n_seeds):
+        cfg, batch, B, N = draw_seed(seed)
         h = FabricHandle(cfg, 0)
         qt, qdt, pt = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
         want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
@@ -95,9 +110,9 @@ def main():
         sel = np.isfinite(want_act).all(0) & np.isfinite(act).all(0) & (rowx >= CLEAR)
         if sel.any():
             worst["action"] = max(worst["action"], float(np.abs(act[:, sel] - want_act[:, sel]).max() / np.abs(want_act[:, sel]).max()))
-        if (seed + 1) % 250 == 0:   # running summary: a run cut short by a time limit still leaves its findings behind
-            print({"seeds_done": seed + 1, "worst_rel_err": worst, "rows_with_nonfinite_results": nonfinite}, flush=True)
-    print({"seeds": n_seeds, "clear_threshold_x": CLEAR, "worst_rel_err": worst, "rows_with_nonfinite_results": nonfinite})
+        if (seed + 1 - first_seed) % 250 == 0:   # running summary: a run cut short by a time limit still leaves its findings behind
+            print({"seeds_done": seed + 1 - first_seed, "first_seed": first_seed, "worst_rel_err": worst, "rows_with_nonfinite_results": nonfinite}, flush=True)
+    print({"seeds": n_seeds, "first_seed": first_seed, "clear_threshold_x": CLEAR, "worst_rel_err": worst, "rows_with_nonfinite_results": nonfinite})
 
 
 if __name__ == "__main__":
