@@ -5,6 +5,10 @@ Barrier leaves behave like 1/x^4 .. 1/x^8, so conditioning degrades towards x ->
 parity bound for x >= 0.05 (the set every other parity test uses) and 1e-8 down to x = 0.01 (measured 4e-10: oracle
 and kernel factor an M with cond ~1e6 by different algorithms); the f32 kernels are characterised bin by bin (bounds =
 measured x ~4).
+x here is the sphere / plane barrier coordinate (scenarios.min_barrier_coordinate); the joints are kept at least 0.1 rad
+from their limits, so the limit leaves (barriers too, x = distance to the limit in rad) never sit below the bin being
+measured in the two lowest bins, and this is a single evaluation -- nothing is stepped into a limit (the rollout soak,
+tests/soak_parity.py, classifies by limit distance as well: DESIGN.md section 3).
 The table is written to gpurun_out/error_vs_barrier.json (copied to profiles/ for the record)."""
 import json
 import os
