@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MRF_ABI_VERSION 2
+#define MRF_ABI_VERSION 3
 #define MRF_MAX_ROBOTS 16
 #define MRF_MAX_SPHERES 32 /* exchanged spheres per robot */
 #define MRF_DOF_MAX 7
@@ -237,7 +237,10 @@ int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int
  *
  * world <= n_robots; further GPUs run replicas of the group on other scenario batches (independent, no exchange).
  * Every rank of the group must make the same sequence of mrf_rollout_sharded calls with the same n_scen.  A timed-out
- * peer exchange is sticky: every later wait of that communicator ends at once, until it is destroyed.
+ * peer exchange is sticky: every later wait of that communicator ends at once, the rollouts it touched leave q/qdot
+ * where they were and return NaN as avg_vel (a result that cannot be mistaken for a rollout), until mrf_comm_reset or
+ * mrf_comm_destroy.  The PEER kernel's grid is capped at the resident workgroup count, so no wait depends on a
+ * workgroup that has not been dispatched.
  *   q_io, qdot_io [dof][n_scen*count]  the OWNED rows, row = scenario*count + (robot - first); advanced in place
  *   params        [MRF_NPARAM][n_scen*count]      avg_vel_out [n_scen*count]
  */
@@ -259,6 +262,11 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
                         void* stream);
 /* Waits for the stream of the last mrf_rollout_sharded and reports a timed-out exchange (MRF_E_LAUNCH) or MRF_OK. */
 int mrf_comm_status(mrf_handle* h);
+/* Clears a timed-out PEER exchange so that the communicator can be used again (the flags carry ever-growing sequence
+ * numbers and need no clearing).  Call it on EVERY rank of the group, after the caller's own barrier: the ranks must
+ * agree on the next mrf_rollout_sharded call.  A no-op for the RCCL transport. */
+int mrf_comm_reset(mrf_handle* h);
+#define MRF_PEER_TIMEOUT_DEFAULT_MS 10000 /* bounded flag wait of the PEER kernel; override: env MRF_PEER_TIMEOUT_MS */
 void mrf_comm_destroy(mrf_handle* h); /* also done by mrf_destroy */
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -364,9 +372,10 @@ int mrf_state_machine_init(mrf_handle* h, int64_t rows, const void* start_goal, 
 /* One update of every row.  x_ee [3][rows] (mrf_control_prepare), start_goal [3][rows],
  * blocks [n_block_arrays][3][rows]: model 0 reads blocks[0] as this step's goal_block (already lifted by 0.1 as the
  * driver does, EXJ:303); model 1 indexes it by the picked count.  q_gripper_io [2][rows] finger joints (model 1 advances
- * them).  Writes x_goal_0 / weight_goal_0 of params_work for the rows whose robot bit is NOT in skip_robot_mask (the
- * RF-CV estimate of mrf_control_prepare overrides the state machine's goal there, EXJ:346-348), and the gripper
- * velocity command gripper_action_out [2][rows] (may be NULL). */
+ * them).  Writes weight_goal_0 of params_work for every row and x_goal_0 for the rows whose robot bit is NOT in
+ * skip_robot_mask (the RF-CV estimate of mrf_control_prepare overrides the state machine's GOAL there, EXJ:346-348; the
+ * weight of an estimated robot is still the state machine's, EXJ:313-316 -> :363), and the gripper velocity command
+ * gripper_action_out [2][rows] (may be NULL). */
 int mrf_state_machine_step(mrf_handle* h, int64_t rows, const mrf_state_machine_config* sm, const void* x_ee,
                            const void* start_goal, const void* blocks, int32_t n_block_arrays, void* q_gripper_io,
                            int32_t* sm_state, void* sm_goal, void* params_work, int32_t skip_robot_mask,

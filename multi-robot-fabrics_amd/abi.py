@@ -6,7 +6,7 @@ The product path has no CPU fallback: if csrc/libmrf_hip.so is missing or cannot
 import ctypes as C
 import os
 
-MRF_ABI_VERSION = 2
+MRF_ABI_VERSION = 3
 MRF_MAX_ROBOTS = 16
 MRF_MAX_SPHERES = 32
 MRF_DOF_MAX = 7
@@ -84,7 +84,7 @@ EXPORTS = [
     "mrf_default_state_machine_config", "mrf_state_machine_config_sizeof", "mrf_state_machine_init", "mrf_state_machine_step",
     "mrf_episode_set_pick_place",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
-    "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_destroy",
+    "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
 ]
 
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2
@@ -224,6 +224,8 @@ def load_library(path=None):
     lib.mrf_rollout_sharded.restype = C.c_int
     lib.mrf_comm_status.argtypes = [vp]
     lib.mrf_comm_status.restype = C.c_int
+    lib.mrf_comm_reset.argtypes = [vp]
+    lib.mrf_comm_reset.restype = C.c_int
     lib.mrf_comm_destroy.argtypes = [vp]
     lib.mrf_comm_destroy.restype = None
     if lib.mrf_abi_version() != MRF_ABI_VERSION:

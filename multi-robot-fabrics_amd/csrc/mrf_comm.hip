@@ -12,8 +12,9 @@
 //                    same scenarios, then folds the other robots' spheres from its LOCAL buffer and finishes the
 //                    solve.  Two buffer generations (step parity) are enough: a rank can publish step k+2 only after
 //                    it has seen every peer's step k+1 flag, which a peer raises after it finished reading step k.
-//                    Workgroup X only ever waits for workgroup X of the peers and workgroups start in index order on
-//                    every rank, so the grid may exceed what is resident at once.
+//                    Block X only ever waits for block X of the peers; the grid is capped at the resident workgroup
+//                    count and each workgroup walks its blocks in increasing order, so no wait can depend on a
+//                    workgroup that is not running.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -59,6 +60,14 @@ __device__ __forceinline__ void xstore(T* p, T v, bool remote) {
     *p = v;
 }
 
+// a quiet NaN by bit pattern (this translation unit is compiled -ffast-math, where NaN literals are undefined)
+template <typename T>
+__device__ __forceinline__ T quiet_nan();
+template <>
+__device__ __forceinline__ double quiet_nan<double>() { return __builtin_bit_cast(double, 0x7ff8000000000000ull); }
+template <>
+__device__ __forceinline__ float quiet_nan<float>() { return __builtin_bit_cast(float, 0x7fc00000u); }
+
 template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict__ cfgp, PeerView V, int64_t n_scen,
                                                       T* __restrict__ q_io, T* __restrict__ qd_io,
@@ -70,22 +79,28 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   const int first = V.first[V.grank], count = V.first[V.grank + 1] - first;
   int cnt_max = 1;
   for (int g = 0; g < V.G; ++g) cnt_max = max(cnt_max, V.first[g + 1] - V.first[g]);
-  const int spw = 64 / cnt_max;  // scenarios per workgroup: the same on every rank, so workgroup X is the same scenarios
+  const int spw = 64 / cnt_max;  // scenarios per block: the same on every rank, so block X is the same scenarios
   const int lane = threadIdx.x;
+  const int nblk = (int)((n_scen + spw - 1) / spw);
+  // The grid is capped at what is resident at once (host side); a workgroup then walks blocks blockIdx.x,
+  // blockIdx.x + gridDim.x, ... in increasing order.  Block X only ever waits for block X of the peers, every workgroup
+  // of every rank is resident and visits its blocks in increasing index order, so the wait graph has no cycle whatever
+  // the dispatch order or the grid size of the other ranks.
+#pragma unroll 1
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
   int ls = lane / count;
   const int l = lane - ls * count;
-  int64_t scen = (int64_t)blockIdx.x * spw + ls;
+  int64_t scen = (int64_t)blk * spw + ls;
   const bool active = ls < spw && scen < n_scen;
-  if (!active) {  // idle lanes shadow the workgroup's first row (no stores)
+  if (!active) {  // idle lanes shadow the block's first row (no stores)
     ls = 0;
-    scen = (int64_t)blockIdx.x * spw;
+    scen = (int64_t)blk * spw;
   }
   const int me = first + (active ? l : 0);
   const int64_t rows = n_scen * count;
   const int64_t row = scen * count + (active ? l : 0);
   const int m01 = LO ? cfg.lo_merge01 : 0, m45 = LO ? cfg.lo_merge45 : 0;
   const int SX = cfg.n_spheres - m01 - m45;
-  const int blk = blockIdx.x;
   int* err = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
 
   PandaState<T> R;
@@ -239,12 +254,19 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
     }
   }
   if (active) {
+    // a timed-out exchange means some step of this rollout folded stale spheres: the state is left where it was and
+    // the velocity signal is NaN, so a caller that forgets mrf_comm_status cannot take the result for a rollout
+    const bool bad = V.G > 1 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (!bad) {
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      q_io[j * rows + row] = R.q[j];
-      qd_io[j * rows + row] = R.qd[j];
+      for (int j = 0; j < 7; ++j) {
+        q_io[j * rows + row] = R.q[j];
+        qd_io[j * rows + row] = R.qd[j];
+      }
     }
-    avg_out[row] = sumsq / (T)(H * 7);  // FPJ:102-116
+    avg_out[row] = bad ? quiet_nan<T>() : sumsq / (T)(H * 7);  // FPJ:102-116
+  }
+  __syncthreads();  // xch is rewritten by the next block of this workgroup
   }
 }
 
@@ -562,21 +584,30 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     int rate_khz = 100000;
     (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, h->device);
     const char* env = std::getenv("MRF_PEER_TIMEOUT_MS");
-    const long long ms = env ? std::atoll(env) : 2000;
-    V.timeout_ticks = (long long)rate_khz * (ms > 0 ? ms : 2000);
+    const long long ms = env ? std::atoll(env) : MRF_PEER_TIMEOUT_DEFAULT_MS;
+    V.timeout_ticks = (long long)rate_khz * (ms > 0 ? ms : MRF_PEER_TIMEOUT_DEFAULT_MS);
     const int spw = 64 / c->cnt_max;
-    dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+    const unsigned nblk = (unsigned)((n_scen + spw - 1) / spw);
     const unsigned long long seq0 = c->seq;
     c->seq += (unsigned long long)H;
     const bool lo = is_link_origin_table(h->cfg);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     return dispatch(h, [&](auto t, auto cl) {
       using T = decltype(t);
       using LS = decltype(cl);
-      if (lo)
-        return launch(h, mrf::k_rollout_peer<T, LS, true>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen,
-                      (T*)q_io, (T*)qdot_io, (const T*)params, (T*)avg_vel_out, seq0);
-      return launch(h, mrf::k_rollout_peer<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen,
-                    (T*)q_io, (T*)qdot_io, (const T*)params, (T*)avg_vel_out, seq0);
+      auto go = [&](auto kernel) {
+        // every workgroup of the launch must be resident: a block waits for the same block of the peers, and a
+        // workgroup that has not started cannot publish (HIP promises no dispatch order)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        const unsigned resident = (unsigned)per_cu * (unsigned)cus;
+        dim3 block(64), grid(nblk < resident ? nblk : resident);
+        return launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen, (T*)q_io, (T*)qdot_io,
+                      (const T*)params, (T*)avg_vel_out, seq0);
+      };
+      if (lo) return go(mrf::k_rollout_peer<T, LS, true>);
+      return go(mrf::k_rollout_peer<T, LS, false>);
     });
   }
 
@@ -623,6 +654,16 @@ int mrf_comm_status(mrf_handle* h) {
     if (err) return fail(h, MRF_E_LAUNCH, "peer exchange timed out: a rank of the group did not publish its spheres "
                                           "(different call sequence, a dead peer, or kernels that cannot run concurrently)");
   }
+  return MRF_OK;
+}
+
+int mrf_comm_reset(mrf_handle* h) {
+  MRF_CHECK_READY(h);
+  Comm* c = (Comm*)h->comm;
+  if (!c) return fail(h, MRF_E_ARG, "no communicator");
+  if (int rc = check_hip(h, hipStreamSynchronize(c->last_stream), "hipStreamSynchronize")) return rc;
+  if (c->transport == MRF_TRANSPORT_PEER)  // the flags carry ever-growing sequence numbers and need no clearing
+    return check_hip(h, hipMemset(c->local + c->off_err, 0, sizeof(int)), "hipMemset");
   return MRF_OK;
 }
 

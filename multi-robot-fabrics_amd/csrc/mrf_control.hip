@@ -295,8 +295,10 @@ __global__ __launch_bounds__(64) void k_state_machine(const DevCfg<T>* __restric
   }
   sg[MRF_SM_WEIGHT * rows + r] = weight;
   const int robot = (int)(r % cfg.n_robots);
-  if (prm && !((skip_mask >> robot) & 1)) {  // EXJ:313-316 -> :423-424
-    for (int c = 0; c < 3; ++c) prm[(MRF_P_X_GOAL_0 + c) * rows + r] = goal[c];
+  if (prm) {  // EXJ:313-316 -> :423-424.  The RF-CV estimate replaces only the GOAL of a masked robot (EXJ:346-348); its
+              // weight still comes from the state machine (get_weight_goal0 -> weight_goals0 of the rollouts, :363)
+    if (!((skip_mask >> robot) & 1))
+      for (int c = 0; c < 3; ++c) prm[(MRF_P_X_GOAL_0 + c) * rows + r] = goal[c];
     prm[MRF_P_WEIGHT_GOAL_0 * rows + r] = weight;
   }
 }

@@ -139,6 +139,8 @@ int mrf_rollout_host(mrf_handle* h, int64_t n_scen, const double* q0, const doub
   MRF_CHECK_READY(h);
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  if (h->cfg.model != MRF_MODEL_PANDA7)  // the segments below are sized 7 x rows: refuse before anything is read
+    return fail(h, MRF_E_CONFIG, "mrf_rollout_host is defined for the panda7 model only");
   const size_t R = (size_t)n_scen * h->cfg.n_robots, H = (size_t)h->cfg.horizon;
   Plan P(h->cfg.scalar == MRF_F64 ? 8 : 4);
   const size_t o_q = P.add_in(q0, 7 * R), o_qd = P.add_in(qdot0, 7 * R), o_p = P.add_in(params, MRF_NPARAM * R);
@@ -157,6 +159,8 @@ int mrf_rollout_cartesian_host(mrf_handle* h, int64_t rows, const double* q0, co
   if (rows == 0) return MRF_OK;
   if (rows < 0 || n_obst < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
   if (n_obst > 0 && (!ox0 || !orad)) return fail(h, MRF_E_ARG, "obstacle arrays missing");
+  if (h->cfg.model != MRF_MODEL_PANDA7)  // the segments below are sized 7 x rows: refuse before anything is read
+    return fail(h, MRF_E_CONFIG, "mrf_rollout_cartesian_host is defined for the panda7 model only");
   const size_t R = (size_t)rows, M = (size_t)n_obst, H = (size_t)h->cfg.horizon;
   Plan P(h->cfg.scalar == MRF_F64 ? 8 : 4);
   const size_t o_q = P.add_in(q0, 7 * R), o_qd = P.add_in(qdot0, 7 * R), o_p = P.add_in(params, MRF_NPARAM * R);
@@ -176,6 +180,8 @@ int mrf_fk_spheres_host(mrf_handle* h, int64_t rows, const double* q, const doub
   if (rows == 0) return MRF_OK;
   if (rows < 0 || !q || !x_out) return fail(h, MRF_E_ARG, "null/negative argument");
   if ((v_out || a_out) && !qdot) return fail(h, MRF_E_ARG, "qdot required for v/a");
+  if (h->cfg.model != MRF_MODEL_PANDA7)  // the segments below are sized 7 x rows: refuse before anything is read
+    return fail(h, MRF_E_CONFIG, "mrf_fk_spheres_host is defined for the panda7 model only");
   const size_t R = (size_t)rows, S = (size_t)h->cfg.n_spheres;
   Plan P(h->cfg.scalar == MRF_F64 ? 8 : 4);
   const size_t o_q = P.add_in(q, 7 * R), o_qd = P.add_in(qdot, 7 * R);

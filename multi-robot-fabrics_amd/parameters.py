@@ -1,10 +1,13 @@
 """Scenario constants and flags of the Panda examples, with the attribute names the reference's drivers read
 (examples/parameters_manipulators.py:4-181, examples/configs/panda_config.yaml:1-8).
 
-Only the planner-facing fields are kept; URDF/tray/table file locations belong to the simulator and are out of scope.
-N > 3 robots (the reference stops at 3, PM:72-73,119-120) use the build-defined ring of config.mount_positions.
+URDF locations (PM:62-79, get_urdf_locations :154) point at the kinematics-only files that tools/make_kinematic_urdf.py
+writes under examples/simulation_environments/urdfs/ (no meshes: there is no physics engine here); the tray / table
+entries are kept as names only.  N > 3 robots (the reference stops at 3, PM:72-73,119-120) use the build-defined ring
+of config.mount_positions.
 """
 import copy
+import os
 
 import numpy as np
 
@@ -12,9 +15,26 @@ from . import config as _config
 from . import scenarios as _scenarios
 
 
+_URDF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "simulation_environments", "urdfs")
+
+
 class manipulator_parameters:
-    def __init__(self, nr_robots, n_obst_per_link=1):
+    def __init__(self, nr_robots, n_obst_per_link=1, urdf_dir=None):
         N = nr_robots
+        urdf_dir = _URDF_DIR if urdf_dir is None else urdf_dir
+        self.URDF_file_panda = os.path.join(urdf_dir, "panda_with_finger.urdf")                 # PM:63
+        self.URDF_file_kinova = os.path.join(urdf_dir, "kinova_gen_3_lite.urdf")                # not shipped
+        shallow = N == 3                                                                          # PM:65-70
+        self.URDF_tray_location = os.path.join(urdf_dir, "tray", "tray_shallow.urdf" if shallow else "tray.urdf")
+        self.URDF_table = os.path.join(urdf_dir, "table", "table_enlarged.urdf" if shallow else "table.urdf")
+        self.urdf_links = {"URDF_file_panda": self.URDF_file_panda, "URDF_file_kinova": self.URDF_file_kinova,
+                           "URDF_tray_location": self.URDF_tray_location, "URDF_table": self.URDF_table}
+        if N == 3:                                                                                # PM:116-118
+            self.tray_positions, self.tray_orientations = [[0.2, 0.77, 0.64], [0.9, -0.63, 0.62]], [[0, 0, 0, 1], [0, 0, 1, 1]]
+            self.table_position = [0.5, 0.4, 0]
+        else:                                                                                     # PM:96-98
+            self.tray_positions, self.tray_orientations = [[0.2, 0.67, 0.57], [0.9, -0.67, 0.57]], [[0, 0, -1, 1], [0, 0, 1, 1]]
+            self.table_position = [0.5, 0, 0]
         self.dt = 0.01                       # PM:8
         self.n_cubes = 6
         self.nr_robots = N
@@ -61,6 +81,9 @@ class manipulator_parameters:
 
     def get_mount_parameters(self):
         return self.mount_param
+
+    def get_urdf_locations(self):
+        return self.urdf_links
 
     def define_settings(self, ROLLOUT_FABRICS=False, ROLLOUTS_PLOTTING=False, STATIC_OR_DYN_FABRICS=0,
                         RESOLVE_DEADLOCKS=True, ESTIMATE_GOAL=False, N_HORIZON=10, MPC_LAYER=False, n_obst_per_link=1):

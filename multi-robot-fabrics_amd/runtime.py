@@ -359,6 +359,10 @@ class FabricHandle:
         """Synchronises the last sharded rollout; raises if a peer exchange timed out."""
         self._check(self.lib.mrf_comm_status(self._h))
 
+    def comm_reset(self):
+        """Clears a timed-out peer exchange (every rank of the group, after a barrier of the caller's)."""
+        self._check(self.lib.mrf_comm_reset(self._h))
+
     def comm_destroy(self):
         self.lib.mrf_comm_destroy(self._h)
 
@@ -495,8 +499,12 @@ class ControlLoop:
         if pick_place is not None:
             pp = dict(pick_place)
             h = h_action
-            self.start_goal = pp["start_goal"].contiguous()
-            self.blocks = pp["blocks"].contiguous()
+            # start_goal and blocks are read IN PLACE by every run() (a caller in model 0 rewrites `blocks` with new
+            # observations between calls): no private copy is made, so they must already be valid device arrays
+            self.start_goal, self.blocks = pp["start_goal"], pp["blocks"]
+            if self.blocks.dim() != 3:
+                raise MrfError(f"blocks: expected [n_block_arrays, 3, {rows}], got {tuple(self.blocks.shape)}")
+            h._arg(self.start_goal, (3, rows), "start_goal")
             self.q_gripper = pp["q_gripper"].clone().contiguous()
             self.sm_cfg = h.state_machine_config(pp["nr_blocks"], model=pp.get("model", 1))
             self.sm_state, self.sm_goal = h.state_machine_state(self.start_goal)

@@ -1,0 +1,261 @@
+"""Kinematic stand-in for the reference's pybullet scene, with the call surface its drivers use
+(examples/simulation_environments/create_simulation_manipulators.py:15-261, urdfenvs' UrdfEnv as the drivers call it:
+example_pandas_Jointspace.py:226-227,285-297,400-405,454).
+
+There is no physics engine in this build.  What the drivers read from the simulator is produced by arithmetic:
+
+  joint state        env.step integrates the velocity command exactly (urdfenvs 'vel' mode): q += dt * action, the
+                     observed velocity is the command; finger joints do the same between their stops [0, 0.04]
+  collision spheres  env.collision_links_poses(): centres from the sphere forward kinematics ON THE DEVICE
+                     (mrf_fk_spheres through kinematics._SphereEvaluator) with the link-local offsets of
+                     add_collision_spheres (SIM:188-245 = config.sphere_offsets_per_link)
+  cubes              ob['robot_0']['FullSensor']['obstacles'][id]['position']: a cube travels with a hand whose
+                     fingers are closing / closed around it (it sits 0.1 below the hand origin, where the driver puts
+                     its grasp target, EXJ:296-297) and stays where the fingers open -- the same minimal model as the
+                     device-resident episodes (include/mrf.h mrf_state_machine_config.model = 1)
+
+`render=True` cannot be honoured (no renderer): it is ignored with a warning, so the reference's default call
+`define_run_panda_example(n_steps=100, render=True)` still runs.
+"""
+import copy
+import random
+import warnings
+
+import numpy as np
+
+from . import config as _config
+from .kinematics import _SphereEvaluator
+
+GRIPPER_OPEN = 0.04          # finger joint upper stop (panda_finger_joint1/2, URDF :621-627)
+GRASP_REACH = 0.03           # a closing gripper takes the cube whose grasp point is this close to the hand [m]
+CUBE_BELOW_HAND = 0.1        # the drivers aim the hand 0.1 above the cube (EXJ:297, EXC:309)
+
+
+class _Geometry(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class BoxObstacle:
+    """The three attributes of mpscenes' BoxObstacle that the reference touches (SIM:68-76): `_config.geometry.position`,
+    `.length`, `.width`."""
+
+    def __init__(self, name, content_dict):
+        self._name = name
+        cfg = _Geometry(copy.deepcopy(content_dict))
+        cfg["geometry"] = _Geometry(cfg["geometry"])
+        self._config = cfg
+
+    def name(self):
+        return self._name
+
+    def position(self):
+        return np.asarray(self._config.geometry.position, dtype=float)
+
+    def size(self):
+        g = self._config.geometry
+        return np.array([g.length, g.width, g.height], dtype=float)
+
+
+class KinematicManipulatorEnv:
+    """What `gym.make("urdf-env-v0", robots=[GenericUrdfReacher(mode="vel")] * N)` is to the drivers."""
+
+    def __init__(self, dt, pos0, mount_transform, link_transforms, collision_links_nrs, render=False):
+        if render:
+            warnings.warn("multi-robot-fabrics_amd has no renderer: render=True is ignored", RuntimeWarning, stacklevel=3)
+        self._dt = float(dt)
+        self._N = len(mount_transform)
+        self._mount = [np.asarray(T, dtype=float) for T in mount_transform]
+        self._q = np.zeros((self._N, 9))
+        self._qdot = np.zeros((self._N, 9))
+        for i in range(self._N):
+            p = np.asarray(pos0[i], dtype=float).reshape(-1)
+            self._q[i, :len(p)] = p
+            if len(p) < 9:                              # PM:111-115 lists two of the three robots without fingers
+                self._q[i, 7:9] = 0.02
+        self._cubes = []                                # [position(3), size(3)]
+        self._cube_ids = []
+        self._held = [None] * self._N                   # (cube index, offset to the hand) in each robot's gripper
+        self._first_id = 2 + self._N                    # pybullet body ids: plane, robots, tray(s)/table come first
+        self._evaluators = []
+        for i in range(self._N):
+            links, offs = [], []
+            for i_link, link_nr in enumerate(collision_links_nrs[i]):
+                for T in link_transforms[i][i_link]:
+                    links.append(min(int(link_nr), 8))
+                    offs.append(np.asarray(T, dtype=float)[0:3, 3])
+            self._evaluators.append(_SphereEvaluator.get(self._mount[i], links, offs))
+        self._hand = [_SphereEvaluator.get(self._mount[i], [8]) for i in range(self._N)]
+        self._sphere_x = None
+        self._closed = False
+
+    # ---------------------------------------------------------------------------------------------- UrdfEnv surface
+    def n(self):
+        return 9 * self._N
+
+    def ns_per_robot(self):
+        return [9] * self._N
+
+    def dt(self):
+        return self._dt
+
+    def add_obstacle(self, obst):
+        self._cubes.append([obst.position().copy(), obst.size().copy()])
+        self._cube_ids.append(self._first_id + len(self._cube_ids))
+
+    def add_sensor(self, sensor, robot_ids):
+        pass
+
+    def set_spaces(self):
+        pass
+
+    def reconfigure_camera(self, *args, **kwargs):
+        pass
+
+    def add_collision_link(self, *args, **kwargs):
+        pass
+
+    def hand_position(self, i_robot):
+        return self._hand[i_robot].eval(self._q[i_robot:i_robot + 1, :7])[0][0, :, 0]
+
+    def _observation(self):
+        sensed = {cid: {"position": c[0].copy(), "size": c[1].copy()} for cid, c in zip(self._cube_ids, self._cubes)}
+        ob = {}
+        for i in range(self._N):
+            ob["robot_%d" % i] = {"joint_state": {"position": self._q[i].copy(), "velocity": self._qdot[i].copy()}}
+        ob["robot_0"]["FullSensor"] = {"obstacles": sensed, "goals": {}}
+        return ob
+
+    def step(self, action):
+        if self._closed:
+            raise RuntimeError("step() on a closed environment")
+        a = np.asarray(action, dtype=float).reshape(self._N, 9)
+        self._q[:, :7] += self._dt * a[:, :7]
+        self._q[:, 7:9] = np.clip(self._q[:, 7:9] + self._dt * a[:, 7:9], 0.0, GRIPPER_OPEN)
+        self._qdot = a.copy()
+        for i in range(self._N):
+            closing = bool((a[i, 7:9] < 0).all())      # the state machine commands -0.05 for as long as it holds (SM:66-72)
+            hand = self.hand_position(i)
+            if not closing:
+                self._held[i] = None                   # fingers opening or idle: the cube stays where it is
+            elif self._held[i] is None:
+                grasp_point = hand - np.array([0.0, 0.0, CUBE_BELOW_HAND])
+                taken = {h[0] for h in self._held if h is not None}
+                d = [np.linalg.norm(c[0] - grasp_point) if k not in taken else np.inf for k, c in enumerate(self._cubes)]
+                if d and min(d) < GRASP_REACH:
+                    k = int(np.argmin(d))
+                    self._held[i] = (k, self._cubes[k][0] - hand)          # the cube keeps its place between the fingers
+            if self._held[i] is not None:
+                k, offset = self._held[i]
+                self._cubes[k][0] = hand + offset
+        return self._observation(), 0.0, False, False, {}
+
+    def update_collision_links(self):
+        self._sphere_x = [ev.eval(self._q[i:i + 1, :7])[0][:, :, 0] for i, ev in enumerate(self._evaluators)]   # [S,3]
+
+    def collision_links_poses(self, position_only=True):
+        """{"<robot>_<sphere>": centre}: the drivers select a robot's spheres by `str(i_robot) in key[0]`
+        (EXJ:404-405, utils_apply_fk.py:21)."""
+        if not position_only:
+            raise NotImplementedError("sphere orientations are not modelled (the drivers ask for positions only)")
+        if self._sphere_x is None:
+            self.update_collision_links()
+        return {"%d_%03d" % (i, s): x.copy() for i, xs in enumerate(self._sphere_x) for s, x in enumerate(xs)}
+
+    def close(self):
+        self._closed = True
+
+
+class create_manipulators_simulation:
+    """create_simulation_manipulators.py:15-261 without pybullet: same constructor argument, same four methods."""
+
+    def __init__(self, params):
+        self.urdf_files = getattr(params, "urdf_links", {})
+        self.z_table = params.mount_param["z_table"]
+        self.mount_positions = params.mount_param["mount_positions"]
+        self.mount_orientations = params.mount_param["mount_orientations"]
+        self.mount_transform = params.mount_transform
+        self.collision_links = params.collision_links
+        self.collision_links_nrs = params.collision_links_nrs
+        self.n_obst_per_link = params.n_obst_per_link
+        self.radius_sphere = params.radius_sphere
+        self.robot_types = params.robot_types
+        self.dt = params.dt
+        self.pos0 = params.pos0
+        self.nr_robots = len(self.robot_types)
+        self.link_transform_list = [[] for _ in range(self.nr_robots)]
+        self.y_trans = 0.2 if self.nr_robots == 3 else 0.0
+        z = self.z_table + 0.07
+        col_a = [[0.4, 0.0, z], [0.4, -0.15, z], [0.4, 0.15, z]]                      # SIM:37-60
+        col_b = [[0.6, -0.15, z], [0.6, 0.0, z], [0.6, 0.15, z]]
+        if self.nr_robots == 2:
+            fixed = {"0": col_a, "1": col_b}
+        elif self.nr_robots == 3:
+            fixed = {"0": col_a[:2], "1": col_b, "2": [col_a[2], col_b[2]]}
+        else:   # build-defined (the reference stops at three robots): cubes 0.45 m in front of every mount
+            fixed = {}
+            for i in range(self.nr_robots):
+                T = np.asarray(self.mount_transform[i], dtype=float)
+                fixed[str(i)] = [list(T[0:3, 3] + T[0:3, 0:3] @ np.array([0.45, dy, 0.0]) + np.array([0, 0, 0.07]))
+                                 for dy in (0.0, -0.15, 0.15)]
+        self.block_xyz_fixed = {k: [[p[0], p[1] + self.y_trans, p[2]] for p in v] for k, v in fixed.items()}
+
+    @staticmethod
+    def check_cube_validity(new_cube, existing_cubes):
+        """SIM:62-76: cubes must not sit on or too close to each other."""
+        slack = 0.06
+        g = new_cube._config.geometry
+        for other in existing_cubes:
+            o = other._config.geometry
+            if np.linalg.norm(np.array(g.position) - np.array(o.position)) <= max(g.length, g.width) / 2 + max(o.length, o.width) / 2 + slack:
+                return False
+        return True
+
+    def _cube(self, k, position):
+        return BoxObstacle(name="cube%d" % k, content_dict={
+            "type": "box", "movable": True,
+            "geometry": {"position": list(position), "orientation": [0, 0, 0, 1], "length": 0.05, "height": 0.05, "width": 0.05}})
+
+    def create_scene(self, random_scene=False, n_cubes=6):
+        """SIM:78-137: n_cubes cubes on the table, drawn at random in the strip between the robots or at fixed places."""
+        obstacles = []
+        if random_scene:
+            while len(obstacles) < n_cubes:
+                cand = self._cube(len(obstacles), [random.uniform(0.4, 0.6), random.uniform(-0.15, 0.15) + self.y_trans,
+                                                   self.z_table + 0.07])
+                if self.check_cube_validity(cand, obstacles):
+                    obstacles.append(cand)
+        else:
+            for i_robot in range(self.nr_robots):
+                for i in range(int(n_cubes / self.nr_robots)):
+                    p = self.block_xyz_fixed[str(i_robot)][i]
+                    obstacles.append(self._cube(len(obstacles), [p[0], p[1], self.z_table + 0.07]))
+        return obstacles
+
+    def initialize_environment(self, render=True, random_scene=False, obstacles=()):
+        """SIM:139-174.  The cubes are put down where pybullet lets them come to rest: on the table top."""
+        self.link_transform_list = [[] for _ in range(self.nr_robots)]
+        links, offs = _config.sphere_offsets_per_link(self.n_obst_per_link)           # SIM:188-245
+        table = {(l, k): off for (l, off), k in zip(zip(links, offs), [s % self.n_obst_per_link for s in range(len(links))])}
+        for i_robot in range(self.nr_robots):
+            for link_nr in self.collision_links_nrs[i_robot]:
+                per_link = []
+                for k in range(self.n_obst_per_link):
+                    T = np.identity(4)
+                    T[0:3, 3] = table[(min(int(link_nr), 8), k)]
+                    per_link.append(T)
+                self.link_transform_list[i_robot].append(per_link)
+        env = KinematicManipulatorEnv(self.dt, self.pos0, self.mount_transform, self.link_transform_list,
+                                      self.collision_links_nrs, render=render)
+        for obst in obstacles:
+            settled = copy.deepcopy(obst)
+            settled._config.geometry.position = [obst._config.geometry.position[0], obst._config.geometry.position[1],
+                                                 self.z_table + obst._config.geometry.height / 2]
+            env.add_obstacle(settled)
+        return env
+
+    def add_collision_spheres(self, env):
+        return env          # the spheres are part of KinematicManipulatorEnv (built from get_link_transforms())
+
+    def get_link_transforms(self):
+        return self.link_transform_list
