@@ -180,8 +180,12 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     out = {}
     a = copy.copy(args)
     a.steps, a.warmup = max(1, min(args.steps, 10)), 1
-    if world > 1:       # the ranks of a robot group work on the same scenarios: one batch per replica, made once
-        batch = ShardedRollout.replica_batch(cfg_roll, args.scenarios, rank, world)
+    from multi_robot_fabrics_amd import sharded
+    # the first (largest) group works on the headline's per-GPU batch; a group with more robots per rank gets
+    # proportionally fewer scenarios (sharded.group_scenarios), so that all ranks finish together
+    a.scenarios = args.scenarios * sharded.robots_per_rank_max(cfg_roll.n_robots, sharded.group_layout(cfg_roll.n_robots, world)[0])
+    if world > 1:       # the ranks of a robot group work on the same scenarios: one batch per group, made once
+        batch = None
     # two ranks sharing one GPU (the test hook) cannot form an RCCL communicator: only the peer transport runs there
     for transport in (("peer",) if os.environ.get("MRF_BENCH_SHARE_GPU") == "1" else ("rccl", "peer")):
         a.transport = transport
@@ -193,6 +197,25 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
         except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
             out[transport] = {"error": f"{type(e).__name__}: {e}"[:400]}
     return out
+
+
+def run_guarded(fn, seconds, on_timeout):
+    """fn() under a wall-clock watchdog thread: on_timeout() is called from the watchdog if fn has not returned after
+    `seconds` (None: no guard).  on_timeout is expected to end the process."""
+    if seconds is None:
+        return fn()
+    import threading
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(seconds):
+            on_timeout()
+
+    threading.Thread(target=watch, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
 
 
 def single_scenario_latency(h_roll, h_act, batch, N, S, iters=200):
@@ -327,11 +350,7 @@ def main():
         elapsed = float(t.item())
     assert torch.isfinite(avg).all() and torch.isfinite(act).all()
 
-    sharded_block = None
-    if not args.no_robot_shard:
-        args.scenarios = B
-        sharded_block = robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank)
-
+    out = None
     if rank == 0:
         roll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         units = B * N * H                                         # rollout-steps per launch
@@ -386,15 +405,33 @@ def main():
             "roofline": roofline,
         }
         out["parity_spot_check"] = parity_spot_check(cfg_roll, cfg_act, batch, avg, act)
-        if sharded_block is not None:
+
+    # Secondary block: the robot-sharded transports.  Everything the headline line needs is in `out` by now, so a
+    # transport that hangs at world > 1 (first contact of RCCL / the peer exchange with more than one GPU) cannot take
+    # the scenario-sharded numbers with it: a per-rank wall-clock guard has rank 0 emit the line with an error marker
+    # and lets every rank leave through os._exit -- no re-exec, no collective, no GPU call on the way out.
+    if not args.no_robot_shard:
+        args.scenarios = B
+
+        def expired():
+            if rank == 0:
+                out["robot_sharded"] = {"error": f"timeout: the robot-sharded block did not finish within {guard_s:.0f} s"}
+                emit(out)
+            os._exit(0)
+
+        guard_s = float(os.environ.get("MRF_BENCH_SHARD_TIMEOUT_S", "240"))
+        sharded_block = run_guarded(lambda: robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank),
+                                    guard_s if world > 1 else None, expired)
+        if rank == 0:
             out["robot_sharded"] = sharded_block
+    if rank == 0:
         if world == 1:
             out["single_scenario"] = single_scenario_latency(h_roll, h_act, batch, N, S)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_roll, cfg_act, batch)
         emit(out)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    if world > 1:   # the line is out: a peer that already left (guard above) must not keep this rank in the teardown
+        run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: os._exit(0))
 
 
 if __name__ == "__main__":

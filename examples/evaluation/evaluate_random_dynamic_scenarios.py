@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
-"""Counterpart of the reference's examples/evaluation/evaluate_random_dynamic_scenarios.py without a simulator: many
-random pick-and-place scenarios at once, entirely on the device (runtime.ControlLoop = mrf_episode_run with the
-pick-and-place state machine attached), for the reference's three cases (evaluate_random_dynamic_scenarios.py:36-72)
+"""The reference's examples/evaluation/evaluate_random_dynamic_scenarios.py: random pick-and-place scenes for two Pandas
+under the three methods it compares (:36-72)
 
     "dynamic"                      MRDF: compute_action against the other robot's moving spheres, no rollouts
     "rollouts dynamic"             + Rollout Fabrics every control step and the deadlock logic on their velocity signal
-    "rollouts dynamic estimated"   + the other robots' goals are not communicated but estimated (RF-CV): inside the rollouts
-                                   the goal of every robot but the first is x_ee + 0.2 v_ee.  (The reference's drivers
-                                   write that estimate into robot 1's goal list, from where it also reaches robot 1's OWN
-                                   compute_action, EXJ:346-348 -> :423 -- robot 1 then chases its own extrapolated hand;
-                                   ControlLoop(apply_estimate=True) reproduces that literally and no episode succeeds.
-                                   Here the estimate stays inside the rollouts, which is what the method describes.)
+    "rollouts dynamic estimated"   + robot 1's goal is not communicated but estimated (RF-CV), deadlock logic off (:66-68)
 
-Reports what the reference's script tabulates: success rate (all blocks of both robots picked and brought home), time
-to success, minimum sphere clearance / collision episodes -- plus how often the deadlock logic stepped in.
-What stands in for pybullet: exact velocity integration, a block that travels with the closed gripper,
-finger joints that follow their velocity command.  Blocks are drawn on the table inside each robot's reach.  This is a
-behavioural evaluation of the specification at scale (thousands of episodes in seconds), not a parity test.
+with two ways to run them:
 
-usage: python examples/evaluation/evaluate_random_dynamic_scenarios.py [--scenarios 512] [--steps 4000] [--blocks 2]
+  define_run_evaluations(n_steps=100, render=False, n_runs=1)      the reference's entry point (:40) and protocol: n_runs
+        random scenes, each stepped through examples/example_pandas_Jointspace.run_panda_example on the mirrored host
+        classes, the reference's statistics (time to success, collision episodes, minimum clearance, solver / step time,
+        success rate; mean +- std per case) returned as a dictionary and printed as a text table; the solver times of
+        the last case are pickled to `results_dynamic_scenarios` as the reference does (:121-122).
+  run_case(case, params, B, steps, n_blocks, seed)                  the same three cases for THOUSANDS of random scenes at
+        once, entirely on the device (runtime.ControlLoop = mrf_episode_run with the pick-and-place state machine).
+        There the RF-CV estimate stays inside the rollouts (goal_estimate_mask); the reference's driver writes it into
+        robot 1's goal list, from where it also reaches robot 1's OWN compute_action (EXJ:346-348 -> :423), robot 1 then
+        chases its own extrapolated hand -- define_run_evaluations reproduces that literally.
+
+What stands in for pybullet: exact velocity integration, a cube that travels with the closed gripper,
+finger joints that follow their velocity command.  A behavioural evaluation of the specification, not a parity test.
+
+usage: python examples/evaluation/evaluate_random_dynamic_scenarios.py [--runs 2 --steps 7000]
+       python examples/evaluation/evaluate_random_dynamic_scenarios.py --device [--scenarios 512] [--steps 4000] [--blocks 2]
 """
 import argparse
+import copy
 import json
 import math
 import os
+import pickle
 import sys
 import time
 
@@ -33,9 +40,102 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
+import examples.parameters_manipulators
+from examples.example_pandas_Jointspace import define_planners, define_rollout_planners, run_panda_example
+from examples.simulation_environments.create_simulation_manipulators import create_manipulators_simulation
 from multi_robot_fabrics_amd import abi, config
+from multi_robot_fabrics_amd.kinematics import UtilsKinematics
 from multi_robot_fabrics_amd.parameters import manipulator_parameters
 from multi_robot_fabrics_amd.runtime import ControlLoop, FabricHandle
+
+
+def get_std(list_of_std: list) -> float:
+    """:29-38: the standard deviation of pooled runs from the runs' standard deviations."""
+    return float(np.sqrt(sum(std ** 2 for std in list_of_std) / len(list_of_std)))
+
+
+def define_run_evaluations(n_steps=100, render=False, n_runs=1, *, out_path="results_dynamic_scenarios"):
+    """:40-156."""
+    random_scene = True
+    cases = ["dynamic", "rollouts dynamic", "rollouts dynamic estimated"]
+    zero = {c: 0 for c in cases}
+    empty = {c: [] for c in cases}
+    n_success, nr_collision_episodes_all = copy.deepcopy(zero), copy.deepcopy(zero)
+    time2success_all, min_clearance_all, step_time_all, solver_time_all, step_time_std, solver_time_std, success_total = (
+        copy.deepcopy(empty) for _ in range(7))
+    param = examples.parameters_manipulators.manipulator_parameters(nr_robots=2)
+    simulation_class = create_manipulators_simulation(params=param)
+    kinematics_class = UtilsKinematics()
+    random_obstacles = [simulation_class.create_scene(random_scene, n_cubes=param.n_cubes) for _ in range(n_runs)]
+    for case in cases:
+        [ROLLOUT_FABRICS, ROLLOUTS_PLOTTING, STATIC_OR_DYN_FABRICS, RESOLVE_DEADLOCKS, ESTIMATE_GOAL, N_HORIZON, MPC_LAYER] = param.get_settings()
+        if case in ("dynamic", "rollouts dynamic", "rollouts dynamic estimated"):
+            STATIC_OR_DYN_FABRICS = 1
+        if case in ("rollouts static", "rollouts dynamic", "rollouts dynamic estimated"):
+            ROLLOUT_FABRICS = True
+        if case == "rollouts dynamic estimated":
+            ESTIMATE_GOAL, RESOLVE_DEADLOCKS = True, False
+        param.define_settings(ROLLOUT_FABRICS=ROLLOUT_FABRICS, ROLLOUTS_PLOTTING=ROLLOUTS_PLOTTING,
+                              STATIC_OR_DYN_FABRICS=STATIC_OR_DYN_FABRICS, RESOLVE_DEADLOCKS=RESOLVE_DEADLOCKS,
+                              ESTIMATE_GOAL=ESTIMATE_GOAL, N_HORIZON=N_HORIZON, MPC_LAYER=MPC_LAYER)
+        planners, planners_grasp, goal_structs = define_planners(params=param)
+        fk_dict = kinematics_class.define_forward_kinematics(planners, collision_links_nrs=param.collision_links_nrs,
+                                                             collision_links=param.collision_links)
+        forwardplanner = (define_rollout_planners(param, fk_dict=fk_dict, goal_structs=goal_structs, n_steps=100)
+                          if case.startswith("rollouts") else None)
+        results = []
+        for z in range(n_runs):
+            env = simulation_class.initialize_environment(render=render, random_scene=random_scene, obstacles=random_obstacles[z])
+            res = run_panda_example(param, n_steps=n_steps, planners=planners, planners_grasp=planners_grasp,
+                                    goal_structs=goal_structs, env=env, fk_dict=fk_dict, forwardplanner=forwardplanner)
+            env.close()
+            results.append(res)
+            n_success[case] += res["success_rate"]
+            success_total[case].append(res["success_rate"])
+            with np.errstate(all="ignore"):
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")          # nanmax of two NaNs: nobody finished within n_steps
+                    time2success_all[case].append(np.nanmax([res["n_steps_panda"], res["n_steps_robot2"]]) * res["dt"])
+            if res["success_rate"] == 1:
+                min_clearance_all[case].append([res["min clearance"]])
+                if res["min clearance"] < 0:
+                    nr_collision_episodes_all[case] += 1
+            solver_time_all[case].append(res["solver_time_mean"])
+            step_time_all[case].append(res["step_time_mean"])
+            solver_time_std[case].append(res["solver_time_std"])
+            step_time_std[case].append(res["step_time_std"])
+        if out_path:
+            with open(out_path, "wb") as fp:                                                 # :121-122
+                pickle.dump([np.expand_dims(np.array(res["solver_times"]), 0) for res in results], fp)
+
+    def pm(vals, std=None):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = float(np.nanmean(vals)) if len(vals) else float("nan")
+            s_ = float(np.nanstd(vals)) if (std is None and len(vals)) else (get_std(std) if std else float("nan"))
+        return {"mean": m, "std": s_}
+
+    out = {"n_runs": n_runs, "n_steps": n_steps, "cases": {}}
+    for case in cases:
+        n_ok = len(min_clearance_all[case])
+        out["cases"][case] = {
+            "time_to_success_s": pm(time2success_all[case]),
+            "collision_episode_rate": nr_collision_episodes_all[case] / n_ok if n_ok else 0,
+            "min_clearance_m": pm([c[0] for c in min_clearance_all[case]]),
+            "solver_time_s": pm(solver_time_all[case], solver_time_std[case]),
+            "step_time_s": pm(step_time_all[case], step_time_std[case]),
+            "success_rate": {"mean": n_success[case] / n_runs, "std": float(np.nanstd(success_total[case]))}}
+    rows = [["", "Time-to-Success", "# Collision Episodes", "Min Clearance", "Solver-Time", "Step-Time", "Success-Rate"]]
+    f = lambda d: "%.4f+-%.4f" % (d["mean"], d["std"])
+    for case in cases:
+        c = out["cases"][case]
+        rows.append([case, f(c["time_to_success_s"]), "%.8f" % c["collision_episode_rate"], f(c["min_clearance_m"]),
+                     f(c["solver_time_s"]), f(c["step_time_s"]), f(c["success_rate"])])
+    widths = [max(len(r[k]) for r in rows) for k in range(7)]
+    out["table"] = "\n".join(" | ".join(cell.ljust(w) for cell, w in zip(r, widths)) for r in rows)
+    return out
 
 
 def random_blocks(params, B, n_blocks, rng):
@@ -128,14 +228,21 @@ def run_case(case, params, B, steps, n_blocks, seed, monitor=50):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=2)
+    ap.add_argument("--device", action="store_true", help="batched device-resident episodes instead of the host protocol")
     ap.add_argument("--scenarios", type=int, default=512)
-    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--blocks", type=int, default=2)
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--robots", type=int, default=2)
     args = ap.parse_args()
-    params = manipulator_parameters(nr_robots=args.robots, n_obst_per_link=1)
-    params.set_horizon(args.horizon)
-    res = [run_case(c, params, args.scenarios, args.steps, args.blocks, seed=7)
-           for c in ("dynamic", "rollouts dynamic", "rollouts dynamic estimated")]
-    print(json.dumps(res, indent=1))
+    if args.device:
+        params = manipulator_parameters(nr_robots=args.robots, n_obst_per_link=1)
+        params.set_horizon(args.horizon)
+        res = [run_case(c, params, args.scenarios, args.steps or 4000, args.blocks, seed=7)
+               for c in ("dynamic", "rollouts dynamic", "rollouts dynamic estimated")]
+        print(json.dumps(res, indent=1))
+    else:
+        out = define_run_evaluations(n_steps=args.steps or 7000, render=False, n_runs=args.runs)
+        print(out.pop("table"))
+        print(json.dumps(out, indent=1))

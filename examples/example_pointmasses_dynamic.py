@@ -7,7 +7,7 @@ radius_obst_dynamic_j (run_point_example :183-212; accelerations zero: "no depen
 The gym simulator is replaced by arithmetic (acceleration-controlled point masses, dt = 0.01), as in
 example_pointmasses_static.py, whose remarks on creeping contact apply here too.
 
-usage: python examples/example_pointmasses_dynamic.py [--steps 1500]
+usage: python examples/example_pointmasses_dynamic.py [--steps 1000]
 """
 import argparse
 import json
@@ -24,11 +24,14 @@ from multi_robot_fabrics_amd.kinematics import GenericURDFFk
 from multi_robot_fabrics_amd.planner import ParameterizedFabricPlanner
 
 
-def set_planner_point(goal, n_obstacles=2, n_dyn_obstacles=0):
+def set_planner_point(goal, n_obstacles: int = 2, n_dyn_obstacles=0):
     """:101-130."""
-    fk = GenericURDFFk(None, "world", "base_link")
+    degrees_of_freedom = 3
+    with open(os.path.join(ROOT, "examples", "simulation_environments", "urdfs", "pointRobot1.urdf"), "r") as file:
+        urdf = file.read()
+    fk = GenericURDFFk(urdf, "world", "base_link")
     planner = ParameterizedFabricPlanner(
-        3, fk,
+        degrees_of_freedom, fk,
         collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
         collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
     planner.set_components(["base_link"], {}, goal=goal, number_obstacles=n_obstacles,
@@ -37,7 +40,11 @@ def set_planner_point(goal, n_obstacles=2, n_dyn_obstacles=0):
     return planner
 
 
-def run_point_example(n_steps=1500):
+def run_point_example(n_steps=1000, render=True):
+    """The reference's signature (:133); there is no renderer in this build, `render` is ignored with a warning."""
+    if render:
+        import warnings
+        warnings.warn("multi-robot-fabrics_amd has no renderer: render=True is ignored", RuntimeWarning, stacklevel=2)
     obstacles_pos = [[1, 1.25, 0], [1, 3.75, 0], [1, -1.25, 0], [-1.1, 0, 0], [-1.1, 2.5, 0], [-1.1, -2.5, 0]]    # :145
     obstacles_radius = [1, 1, 1, 1, 1, 1]
     robots_pos = np.array([[-2.5, 0.01, 0.0], [-2.5, -2.49, 0.0], [2.5, 1.26, 0.0], [2.5, 3.74, 0.0]])             # :149
@@ -82,5 +89,5 @@ def run_point_example(n_steps=1500):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=1500)
-    print(json.dumps(run_point_example(ap.parse_args().steps), indent=1))
+    ap.add_argument("--steps", type=int, default=1000)
+    print(json.dumps(run_point_example(n_steps=ap.parse_args().steps, render=False), indent=1))

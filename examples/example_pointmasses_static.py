@@ -8,7 +8,7 @@ a robot that is pushed against an obstacle while it creeps (xdot -> 0 makes the 
 arbitrarily close, and where pybullet would stop it at the surface this loop reports `first_contact_step` and goes on
 (robot 3 is squeezed between two scene spheres on its diagonal after ~6 s; the CPU oracle does the same with dt = 0.002).
 
-usage: python examples/example_pointmasses_static.py [--steps 1500]
+usage: python examples/example_pointmasses_static.py [--steps 1000]
 """
 import argparse
 import json
@@ -25,11 +25,14 @@ from multi_robot_fabrics_amd.kinematics import GenericURDFFk
 from multi_robot_fabrics_amd.planner import ParameterizedFabricPlanner
 
 
-def set_planner_point(goal, n_obstacles=2):
+def set_planner_point(goal, n_obstacles: int = 2, degrees_of_freedom: int = 7, obstacle_resolution=1):
     """:102-129."""
-    fk = GenericURDFFk(None, "world", "base_link")
+    degrees_of_freedom = 3                      # the reference overrides its own argument the same way
+    with open(os.path.join(ROOT, "examples", "simulation_environments", "urdfs", "pointRobot1.urdf"), "r") as file:
+        urdf = file.read()
+    fk = GenericURDFFk(urdf, "world", "base_link")
     planner = ParameterizedFabricPlanner(
-        3, fk,
+        degrees_of_freedom, fk,
         collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
         collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
     planner.set_components(["base_link"], {}, goal=goal, number_obstacles=n_obstacles)
@@ -37,7 +40,11 @@ def set_planner_point(goal, n_obstacles=2):
     return planner
 
 
-def run_point_example(n_steps=1500):
+def run_point_example(n_steps=1000, render=True):
+    """The reference's signature (:131); there is no renderer in this build, `render` is ignored with a warning."""
+    if render:
+        import warnings
+        warnings.warn("multi-robot-fabrics_amd has no renderer: render=True is ignored", RuntimeWarning, stacklevel=2)
     obstacles_pos = [[1, 1.25, 0], [1, 3.75, 0], [1, -1.25, 0], [-1.1, 0, 0], [-1.1, 2.5, 0], [-1.1, -2.5, 0]]    # :142
     obstacles_radius = [1, 1, 1, 1, 1, 1]
     robots_pos = np.array([[-2.5, 0.01, 0.0], [-2.5, -2.49, 0.0], [2.5, 1.26, 0.0], [2.5, 3.74, 0.0]])             # :146
@@ -76,5 +83,5 @@ def run_point_example(n_steps=1500):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=1500)
-    print(json.dumps(run_point_example(ap.parse_args().steps), indent=1))
+    ap.add_argument("--steps", type=int, default=1000)
+    print(json.dumps(run_point_example(n_steps=ap.parse_args().steps, render=False), indent=1))

@@ -32,7 +32,12 @@ CUBE_BELOW_HAND = 0.1        # the drivers aim the hand 0.1 above the cube (EXJ:
 
 
 class _Geometry(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key) from None
+
     __setattr__ = dict.__setitem__
 
 
@@ -248,10 +253,9 @@ class create_manipulators_simulation:
         env = KinematicManipulatorEnv(self.dt, self.pos0, self.mount_transform, self.link_transform_list,
                                       self.collision_links_nrs, render=render)
         for obst in obstacles:
-            settled = copy.deepcopy(obst)
-            settled._config.geometry.position = [obst._config.geometry.position[0], obst._config.geometry.position[1],
-                                                 self.z_table + obst._config.geometry.height / 2]
-            env.add_obstacle(settled)
+            g = dict(obst._config.geometry)
+            g["position"] = [g["position"][0], g["position"][1], self.z_table + g["height"] / 2]
+            env.add_obstacle(BoxObstacle(obst.name(), dict(obst._config, geometry=g)))
         return env
 
     def add_collision_spheres(self, env):

@@ -1,11 +1,15 @@
 """Robot-sharded Rollout Fabrics: one robot (or a contiguous group of robots) per GPU, with an all-gather of the
 predicted collision-sphere states after every rollout step (the exchange step is FPJ:211-225).
 
-    world = G x D    G ranks share the robots of a scenario (G = largest divisor of world that is <= N),
-                     D data-parallel replicas of that group split the scenario batch.
+    world = sum of group sizes   the ranks are filled with groups of N ranks (one robot per GPU, the north-star layout),
+                     then ONE smaller group takes the remaining ranks: 3 robots on 1/2/4/8 GPUs -> [1], [2], [3, 1],
+                     [3, 3, 2]; 8 robots on 8 GPUs -> [8].  Inside a group the robots are split into contiguous blocks
+                     whose sizes differ by at most one (mrf_comm_partition); the groups are data-parallel replicas on
+                     different scenario batches, sized in inverse proportion to the group's robots per rank so that
+                     all ranks finish together.
     per rollout step on every rank:
         mrf_step_predict   q += dt*qdot for the owned robots; their spheres (x, v, a) -> sph_own [cnt, S, 9, B]
-        all_gather         over the G ranks of the replica (RCCL over xGMI on GPUs; gloo in the CPU tests)
+        all_gather         over the ranks of the group (RCCL over xGMI on GPUs; gloo in the CPU tests)
         mrf_step_action    fabric solve of the owned robots against everybody else's spheres; qdot := action
 
 Three transports for the exchange:
@@ -30,10 +34,33 @@ import torch.distributed as dist
 from . import abi
 
 
-def robot_groups(n_robots, world):
-    """-> (G, D): ranks per scenario group and number of data-parallel replicas."""
-    G = max(g for g in range(1, min(world, n_robots) + 1) if world % g == 0)
-    return G, world // G
+def group_layout(n_robots, world):
+    """Sizes of the robot groups that `world` ranks form: groups of n_robots ranks (one robot per rank) first, then one
+    smaller group with the ranks that are left ("G <= N, remaining GPUs split the scenario batch")."""
+    if world < 1 or n_robots < 1:
+        raise ValueError("world and n_robots must be positive")
+    full, rem = divmod(world, n_robots)
+    return [n_robots] * full + ([rem] if rem else [])
+
+
+def rank_placement(n_robots, world, rank):
+    """-> (group index, rank inside the group, first global rank of the group, group size)."""
+    first = 0
+    for gi, size in enumerate(group_layout(n_robots, world)):
+        if rank < first + size:
+            return gi, rank - first, first, size
+        first += size
+    raise ValueError(f"rank {rank} outside world {world}")
+
+
+def robots_per_rank_max(n_robots, G):
+    return -(-n_robots // G)
+
+
+def group_scenarios(n_robots, world, scenarios):
+    """Scenario batch of every group when a one-robot-per-rank group gets `scenarios`: a group whose ranks carry c
+    robots each takes scenarios // c, so that a rollout costs every rank of the job about the same time."""
+    return [max(1, scenarios // robots_per_rank_max(n_robots, size)) for size in group_layout(n_robots, world)]
 
 
 def robot_partition(n_robots, G):
@@ -69,8 +96,9 @@ class ShardedRollout:
         self.cfg = cfg.copy()
         self.N, self.S, self.H = cfg.n_robots, cfg.n_spheres, cfg.horizon
         self.rank, self.world = rank, world
-        self.G, self.D = robot_groups(self.N, world)
-        self.replica, self.grank = divmod(rank, self.G)
+        self.groups = group_layout(self.N, world)
+        self.replica, self.grank, self.group_first, self.G = rank_placement(self.N, world, rank)
+        self.D = len(self.groups)
         self.parts = robot_partition(self.N, self.G)
         self.first, self.count = self.parts[self.grank]
         self.cnt_max = max(c for _, c in self.parts)
@@ -81,11 +109,12 @@ class ShardedRollout:
         self.group = None
         if world > 1:
             # one communicator per replica; every rank must take part in every new_group call
-            for d in range(self.D):
-                ranks = list(range(d * self.G, (d + 1) * self.G))
-                g = dist.new_group(ranks=ranks) if self.G > 1 else None
+            first = 0
+            for d, size in enumerate(self.groups):
+                g = dist.new_group(ranks=list(range(first, first + size))) if size > 1 else None
                 if d == self.replica:
                     self.group = g
+                first += size
         if not self.uniform:
             # scatter plan from the padded gather buffer [G, cnt_max] to robots [N]
             idx = []
@@ -109,7 +138,7 @@ class ShardedRollout:
                     except Exception as e:       # noqa: BLE001
                         box = ["ERR " + str(e)]
                 if self.G > 1:
-                    dist.broadcast_object_list(box, src=self.replica * self.G, group=self.group)
+                    dist.broadcast_object_list(box, src=self.group_first, group=self.group)
                 if isinstance(box[0], str):
                     err = box[0]
                 else:
@@ -176,12 +205,16 @@ class ShardedRollout:
     @staticmethod
     def bench(cfg, batch, args, rank, world, local_rank):
         import numpy as np
-        B = args.scenarios
         transport = getattr(args, "transport", "rccl")
+        per_group = group_scenarios(cfg.n_robots, world, args.scenarios)
+        gi = rank_placement(cfg.n_robots, world, rank)[0]
+        B = per_group[gi]              # this group's batch: args.scenarios for a one-robot-per-rank group
         sr = ShardedRollout(cfg, rank, world, device_index=local_rank, transport=transport, max_scenarios=B)
         if batch is None:
-            # the ranks of one robot group work on the SAME scenarios (one batch per replica)
+            # the ranks of one robot group work on the SAME scenarios (one batch per group)
             batch = ShardedRollout.replica_batch(cfg, B, rank, world)
+        elif batch["q"].shape[1] != B * cfg.n_robots:
+            batch = {k: v[:, :B * cfg.n_robots] for k, v in batch.items() if hasattr(v, "shape") and v.ndim == 2}
         rows = sr.own_rows(B).numpy()
         h = sr.backend.h
         q0, qd0, prm = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
@@ -220,13 +253,15 @@ class ShardedRollout:
             perr = float(t.item())
         N, H, S = cfg.n_robots, cfg.horizon, sr.S
         sb = 8 if cfg.scalar == abi.F64 else 4
-        rate = sr.D * B * args.steps / elapsed
+        rate = sum(per_group) * args.steps / elapsed            # every group's scenarios over the slowest rank's time
+        per_rank = [c for size in sr.groups for _, c in robot_partition(N, size)]
         return {
             "metric": f"rollout control-steps/s, {N}-Panda RF-CV H={H}, robots sharded over GPUs with per-step all-gather",
             "value": rate, "unit": "control-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{N}-Panda RF-CV H={H} coupled rollout only", "scenarios_per_replica": B,
+                       "robot_groups": sr.groups, "scenarios_per_group": per_group, "robots_per_rank_all": per_rank,
                        "robot_group_ranks": sr.G, "replicas": sr.D, "robots_per_rank": [c for _, c in sr.parts],
                        "sharding": "robots (all-gather of SX*9*B sphere scalars per robot per rollout step)",
                        "exchanged_spheres_per_robot": S},
@@ -241,8 +276,7 @@ class ShardedRollout:
     @staticmethod
     def replica_batch(cfg, B, rank, world):
         from . import scenarios
-        G, _ = robot_groups(cfg.n_robots, world)
-        return scenarios.panda_batch(cfg, B, seed=1000 + rank // G)
+        return scenarios.panda_batch(cfg, B, seed=1000 + rank_placement(cfg.n_robots, world, rank)[0])
 
     @staticmethod
     def roofline(cfg, sr, B, sb, seconds_per_rollout):

@@ -10,6 +10,11 @@ Writes tests/golden/reference_static.npz (data only):
   pm{2,3}_*             attributes of examples/parameters_manipulators.manipulator_parameters(nr_robots) (numpy-only
                         module, imported from the reference) that the planner-facing code reads
   yaml_*                the eight keys of examples/configs/panda_config.yaml
+  sig_*                 the call contract of the example / evaluation entry points (examples/test_examples.py:8-36 calls
+                        them as f(n_steps=100, render=False)): "module:function" names with their parameter names and the
+                        repr of their defaults, read from the reference's files with `ast` (nothing is imported)
+  result_keys_*         keys of the dictionary run_panda_example returns (example_pandas_Jointspace.py:509-515,
+                        example_pandas_cartesian.py:518-523)
 """
 import argparse
 import importlib.util
@@ -89,6 +94,39 @@ def parameters(ref_root, n):
     return out
 
 
+ENTRY_POINTS = {
+    "examples/example_pandas_Jointspace.py": ["create_dummy_goal_panda", "set_planner_panda", "define_planners",
+                                              "define_rollout_planners", "run_panda_example", "define_run_panda_example"],
+    "examples/example_pandas_cartesian.py": ["create_dummy_goal_panda", "set_planner_panda", "define_planners",
+                                             "define_rollout_planners", "run_panda_example", "define_run_panda_example"],
+    "examples/example_pointmasses_static.py": ["set_planner_point", "run_point_example"],
+    "examples/example_pointmasses_dynamic.py": ["set_planner_point", "run_point_example"],
+    "examples/evaluation/evaluate_horizon.py": ["get_std", "define_run_evaluations"],
+    "examples/evaluation/evaluate_random_dynamic_scenarios.py": ["get_std", "define_run_evaluations"],
+}
+
+
+def entry_point_contract(ref_root):
+    """[(module:function, "name=default,name,...")] and the result keys of the two run_panda_example functions."""
+    import ast
+    names, params, result_keys = [], [], {}
+    for rel, funcs in ENTRY_POINTS.items():
+        with open(os.path.join(ref_root, rel)) as f:
+            tree = ast.parse(f.read())
+        defs = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+        for fn in funcs:
+            a = defs[fn].args
+            pos = a.posonlyargs + a.args
+            defaults = [None] * (len(pos) - len(a.defaults)) + list(a.defaults)
+            items = [arg.arg if d is None else f"{arg.arg}={ast.unparse(d)}" for arg, d in zip(pos, defaults)]
+            names.append(f"{rel}:{fn}")
+            params.append(",".join(items))
+        if "run_panda_example" in defs:
+            ret = [n for n in ast.walk(defs["run_panda_example"]) if isinstance(n, ast.Return) and isinstance(n.value, ast.Dict)]
+            result_keys[rel] = [k.value for k in ret[-1].value.keys]
+    return names, params, result_keys
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("MRF_REFERENCE", "/root/reference"))
@@ -115,6 +153,33 @@ def main():
     out["results_horizon_dtype"] = np.array(str(np.asarray(rec[0]).dtype))
     out["results_horizon_mean_s"] = np.array([float(np.asarray(r).mean()) for r in rec])
     out["results_horizon_median_s"] = np.array([float(np.median(np.asarray(r))) for r in rec])
+    names, params, result_keys = entry_point_contract(ref)
+    out["sig_names"], out["sig_params"] = np.array(names), np.array(params)
+    out["result_keys_jointspace"] = np.array(result_keys["examples/example_pandas_Jointspace.py"])
+    out["result_keys_cartesian"] = np.array(result_keys["examples/example_pandas_cartesian.py"])
+    for n in (2, 3):      # simulator-facing attributes of manipulator_parameters that the scene stand-in reads
+        spec = importlib.util.spec_from_file_location("ref_pm", os.path.join(ref, "examples", "parameters_manipulators.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _np = mod.np
+
+        class _Np:
+            def __getattr__(self, k):
+                return getattr(_np, k)
+
+            @staticmethod
+            def array(x, *a, **kw):
+                try:
+                    return _np.array(x, *a, **kw)
+                except ValueError:
+                    return _np.array(x, dtype=object)
+        mod.np = _Np()
+        p = mod.manipulator_parameters(nr_robots=n)
+        out[f"pm{n}_urdf_link_keys"] = np.array(sorted(p.get_urdf_locations()))
+        out[f"pm{n}_urdf_basenames"] = np.array([os.path.basename(p.get_urdf_locations()[k]) for k in sorted(p.get_urdf_locations())])
+        out[f"pm{n}_tray_positions"] = np.array(p.tray_positions, dtype=float)
+        out[f"pm{n}_tray_orientations"] = np.array(p.tray_orientations, dtype=float)
+        out[f"pm{n}_table_position"] = np.array(p.table_position, dtype=float)
     np.savez(os.path.join(HERE, "reference_static.npz"), **out)
     print("wrote reference_static.npz:", len(out), "arrays;", "joint order", order[:18])
 

@@ -68,5 +68,31 @@ def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
     assert r["n_gpus"] == 2 and r["transport"] == "peer"
     assert r["config"]["robot_group_ranks"] == 2 and r["config"]["robots_per_rank"] == [2, 1]
     assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]
-    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 2 * 6 * 9 * 2016 * 8
-    assert r["allgather_bytes_per_rank_per_step"] == 2 * 6 * 9 * 2016 * 8
+    # 3 robots on 2 ranks: one group [2] whose ranks carry up to 2 robots -> half the scenarios of a 1-robot-per-rank group
+    assert r["config"]["robot_groups"] == [2] and r["config"]["scenarios_per_group"] == [1008]
+    assert r["config"]["robots_per_rank_all"] == [2, 1]
+    assert abs(r["value"] - 1008 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
+    # both roofline views at world > 1: the link the exchange crosses and the algorithmic HBM bytes of the exchanged formulation
+    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 2 * 6 * 9 * 1008 * 8
+    assert r["roofline"]["link"]["frac"] > 0 and r["roofline"]["hbm_algorithmic"]["frac"] > 0
+    assert r["roofline"]["hbm_algorithmic"]["bytes_per_unit"] > 0
+    assert r["allgather_bytes_per_rank_per_step"] == 2 * 6 * 9 * 1008 * 8
+
+
+def test_stuck_secondary_block_cannot_take_the_headline_with_it():
+    """The wall-clock guard around the robot-sharded block (bench.py run_guarded): with a guard far shorter than the
+    block, rank 0 still emits the scenario-sharded headline -- with an error marker in place of the block -- and every
+    rank leaves with exit code 0."""
+    env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_BENCH_SHARD_TIMEOUT_S="0.01")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenarios", "2016"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_spot_check"]["ok"]
+    # rank 0's own guard normally fires first; if the other rank's exit reaches it earlier, the block reports that instead
+    err = r["robot_sharded"].get("error") or r["robot_sharded"]["peer"]["error"]
+    assert err and ("timeout" in err or "Error" in err)

@@ -212,12 +212,26 @@ def test_urdf_constants_are_checked():
 
 # ------------------------------------------------------------------------------------------ sharding plan
 def test_robot_groups_and_partition():
-    assert sharded.robot_groups(3, 1) == (1, 1)
-    assert sharded.robot_groups(3, 2) == (2, 1)
-    assert sharded.robot_groups(3, 4) == (2, 2)
-    assert sharded.robot_groups(3, 8) == (2, 4)
-    assert sharded.robot_groups(8, 8) == (8, 1)
-    assert sharded.robot_groups(8, 4) == (4, 1)
+    # groups of N ranks (one robot per GPU: BASELINE config 4 "robots sharded 1/GPU"), then one smaller group
+    assert sharded.group_layout(3, 1) == [1]
+    assert sharded.group_layout(3, 2) == [2]
+    assert sharded.group_layout(3, 3) == [3]
+    assert sharded.group_layout(3, 4) == [3, 1]
+    assert sharded.group_layout(3, 8) == [3, 3, 2]
+    assert sharded.group_layout(8, 8) == [8]
+    assert sharded.group_layout(8, 4) == [4]
+    assert sharded.group_layout(2, 8) == [2, 2, 2, 2]
+    assert [sharded.rank_placement(3, 8, r) for r in range(8)] == [
+        (0, 0, 0, 3), (0, 1, 0, 3), (0, 2, 0, 3), (1, 0, 3, 3), (1, 1, 3, 3), (1, 2, 3, 3), (2, 0, 6, 2), (2, 1, 6, 2)]
+    assert sharded.rank_placement(3, 4, 3) == (1, 0, 3, 1)
+    # a group's scenario share is inversely proportional to its robots per rank: the ranks finish together
+    assert sharded.group_scenarios(3, 8, 1200) == [1200, 1200, 600]
+    assert sharded.group_scenarios(3, 4, 1200) == [1200, 400]
+    assert sharded.group_scenarios(8, 8, 1200) == [1200] and sharded.group_scenarios(3, 1, 1200) == [400]
+    for n in range(1, 9):
+        for w in range(1, 17):
+            sizes = sharded.group_layout(n, w)
+            assert sum(sizes) == w and all(1 <= g <= n for g in sizes) and sizes == sorted(sizes, reverse=True)
     assert sharded.robot_partition(3, 2) == [(0, 2), (2, 1)]
     assert sharded.robot_partition(8, 4) == [(0, 2), (2, 2), (4, 2), (6, 2)]
     for n in range(1, 17):

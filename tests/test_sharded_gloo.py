@@ -95,7 +95,8 @@ def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir):
         qd = torch.from_numpy(np.ascontiguousarray(batch["qdot"][:, rows]))
         prm = torch.from_numpy(np.ascontiguousarray(batch["params"][:, rows]))
         avg = sr.rollout(q, qd, prm)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows, avg=avg.numpy(), q=q.numpy(), qd=qd.numpy())
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rows=rows, avg=avg.numpy(), q=q.numpy(), qd=qd.numpy(),
+                 group=sr.replica, grank=sr.grank, gsize=sr.G)
     finally:
         dist.destroy_process_group()
 
@@ -123,6 +124,30 @@ def test_sharded_rollout_world2_matches_fused(oracle, tmp_path, n_robots):
         assert np.abs(d["q"] - want_q[-1][:, rows]).max() < 1e-12
         assert np.abs(d["qd"] - want_qd[-1][:, rows]).max() < 1e-11
     assert sorted(seen) == list(range(B * n_robots))       # every (scenario, robot) row owned exactly once
+
+
+def test_sharded_rollout_world4_three_robots_one_per_rank_plus_a_group_of_one(oracle, tmp_path):
+    """BASELINE config 4 on the 1/2/4/8 ladder: 3 robots on 4 ranks form the groups [3] + [1] (sharded.group_layout) --
+    ranks 0..2 own one robot each and exchange spheres every step, rank 3 is a replica that carries all three robots and
+    exchanges nothing.  Both groups must reproduce the fused rollout."""
+    world, n_robots, H, B = 4, 3, 3, 4
+    assert sharded.group_layout(n_robots, world) == [3, 1]
+    mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path)), nprocs=world, join=True)
+    cfg = config.panda_config(n_robots=n_robots, horizon=H)
+    cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1
+    batch = scenarios.panda_batch(cfg, B, seed=77, x_min=0.08)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    seen = {0: [], 1: []}
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        rows = d["rows"]
+        assert (int(d["group"]), int(d["grank"]), int(d["gsize"])) == ((0, r, 3) if r < 3 else (1, 0, 1))
+        assert len(rows) == (B if r < 3 else 3 * B)                       # one robot per rank / all robots
+        seen[int(d["group"])] += list(rows)
+        assert np.abs(d["avg"] - want_avg[rows]).max() < 1e-12 * max(1.0, np.abs(want_avg).max())
+        assert np.abs(d["q"] - want_q[-1][:, rows]).max() < 1e-12
+        assert np.abs(d["qd"] - want_qd[-1][:, rows]).max() < 1e-11
+    assert sorted(seen[0]) == sorted(seen[1]) == list(range(B * n_robots))
 
 
 def test_single_rank_needs_no_process_group(oracle):
