@@ -81,6 +81,22 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
     from multi_robot_fabrics_amd import scenarios
 
     N, H = cfg_roll.n_robots, cfg_roll.horizon
+    # The shipped oracle/libmrf_oracle.so was compiled in the build container for the x86-64-v3 baseline.  The baseline
+    # is timed on THIS node's cores, so rebuild the same source here with -march=native when a compiler is present
+    # (CPU code, outside every timed GPU region) and say which build was timed.
+    import socket
+    import tempfile
+    native = oracle_lib.build_native(tempfile.mkdtemp(prefix="mrf_oracle_"))
+    if native:
+        oracle_lib.use_library(native)
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), None)
+    except OSError:
+        pass
+    build_note = (f"-O3 -march=native, built on the timed node ({socket.gethostname()})" if native else
+                  "-O3 -march=x86-64-v3, built in the build container (no compiler on the timed node)")
 
     def control_steps(n_scen):
         sel = slice(0, n_scen * N)
@@ -138,8 +154,10 @@ def cpu_baseline(cfg_roll, cfg_act, batch, target_s=8.0):
         "cores": int(min(best["threads"], math.ceil(quota))) if quota else best["threads"], "threads": best["threads"],
         "kind": "port",
         "sample": f"{best['scenarios']} scenarios of the same workload, one control step each, {best['seconds']:.1f} s; "
-                  f"float64 C++ restatement (oracle/mrf_oracle.cpp, -O3 -march=native, OpenMP one scenario per thread); "
+                  f"float64 C++ restatement (oracle/mrf_oracle.cpp, {build_note}, OpenMP one scenario per thread); "
                   f"thread count chosen by a sweep over {cands}",
+        "oracle_built_on": socket.gethostname() if native else "build container", "march": "native" if native else "x86-64-v3",
+        "cpu_model": cpu_model,
         "single_thread_value": out["single"]["rate"], "host_cores": ncores, "sched_getaffinity_cores": usable,
         "cgroup_cpu_quota_cores": quota,
         "thread_sweep_control_steps_per_s": {str(k): v for k, v in probe.items()},
@@ -276,6 +294,7 @@ def main():
     share_gpu = os.environ.get("MRF_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+        os.environ.setdefault("MRF_PEER_DEVICE_SHARE", str(world))    # the ranks' peer kernels share one device's slots
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
@@ -389,6 +408,12 @@ def main():
             roofline = dict(hbm_alg, traffic=traffic, traffic_source=traffic_src)
         roofline.update({"kernel": "k_rollout_panda", "units_per_launch": units, "kernel_ms": roll_ms,
                          "hbm_algorithmic": hbm_alg})
+        # the counters behind flops_per_unit / traffic belong to one version of the kernel sources (stamped by
+        # tools/make_traffic.py): say so when the sources in this tree are not that version
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from make_traffic import kernel_source_sha256
+        stamp = (src or {}).get("kernel_source_sha256")
+        roofline["roofline_inputs_stale"] = bool(src is None or stamp != kernel_source_sha256())
         control_rate = world * B * args.steps / elapsed
         out = {
             "metric": "planner control-steps/s (rollout + per-robot compute_action), 3-Panda RF-CV H=30"

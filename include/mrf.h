@@ -267,6 +267,8 @@ int mrf_comm_status(mrf_handle* h);
  * agree on the next mrf_rollout_sharded call.  A no-op for the RCCL transport. */
 int mrf_comm_reset(mrf_handle* h);
 #define MRF_PEER_TIMEOUT_DEFAULT_MS 10000 /* bounded flag wait of the PEER kernel; override: env MRF_PEER_TIMEOUT_MS */
+/* env MRF_PEER_DEVICE_SHARE = k: k ranks of a group run on ONE device (single-GPU test setups); the PEER kernel then caps
+ * its grid at 1/k of the device's resident workgroups so that all k kernels fit at once. */
 void mrf_comm_destroy(mrf_handle* h); /* also done by mrf_destroy */
 
 /* ------------------------------------------------------------------------------------------------------------

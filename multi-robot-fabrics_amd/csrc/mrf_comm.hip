@@ -601,7 +601,13 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         // workgroup that has not started cannot publish (HIP promises no dispatch order)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        const unsigned resident = (unsigned)per_cu * (unsigned)cus;
+        unsigned resident = (unsigned)per_cu * (unsigned)cus;
+        // several ranks on ONE device (the single-GPU test hook) share its workgroup slots: MRF_PEER_DEVICE_SHARE = number
+        // of processes whose peer kernels must be resident together
+        if (const char* sh = std::getenv("MRF_PEER_DEVICE_SHARE")) {
+          const int k = std::atoi(sh);
+          if (k > 1) resident = resident / (unsigned)k ? resident / (unsigned)k : 1u;
+        }
         dim3 block(64), grid(nblk < resident ? nblk : resident);
         return launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen, (T*)q_io, (T*)qdot_io,
                       (const T*)params, (T*)avg_vel_out, seq0);

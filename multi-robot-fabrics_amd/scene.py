@@ -225,11 +225,19 @@ class create_manipulators_simulation:
         """SIM:78-137: n_cubes cubes on the table, drawn at random in the strip between the robots or at fixed places."""
         obstacles = []
         if random_scene:
+            # rejection sampling as in the reference; six cubes 0.11 m apart barely fit the 0.2 x 0.3 m strip, and an
+            # unlucky start can leave no room for the last ones -- the reference then loops forever, here the draw
+            # starts over after a bounded number of rejected candidates
+            rejected = 0
             while len(obstacles) < n_cubes:
                 cand = self._cube(len(obstacles), [random.uniform(0.4, 0.6), random.uniform(-0.15, 0.15) + self.y_trans,
                                                    self.z_table + 0.07])
                 if self.check_cube_validity(cand, obstacles):
                     obstacles.append(cand)
+                else:
+                    rejected += 1
+                    if rejected > 200:
+                        obstacles, rejected = [], 0
         else:
             for i_robot in range(self.nr_robots):
                 for i in range(int(n_cubes / self.nr_robots)):

@@ -457,3 +457,30 @@ def rollout_jointspace(planners, q0, qdot0, params, H, dt=0.01, dynamic=True, sp
             qds[i].append(qd[i].copy())
     avg = [sum(float(np.sum(v ** 2)) for v in qds[i]) / (H * 7) for i in range(N)]   # FPJ:102-116
     return np.array(qs), np.array(qds), np.array(avg)
+
+
+def rollout_cartesian(planner, q0, qdot0, params, x_obsts_dyn, v_obsts_dyn, a_obsts_dyn, radius_obsts_dyn, H, dt=0.01):
+    """Per-robot rollout of forward_planner_Cartesian.py:421-458 ('vel' mode): action at the current state against the
+    obstacles at their current positions, then q += dt * action, then every obstacle advances with its constant
+    velocity (x_o += dt * v_o; the accelerations a_o are passed through unchanged, FPC:422-427).
+    Returns (q_traj[H][7], qdot_traj[H][7], avg_vel)."""
+    q, qd = np.array(q0, dtype=float), np.array(qdot0, dtype=float)
+    ox = [np.array(x, dtype=float) for x in x_obsts_dyn]
+    ov = [np.array(v, dtype=float) for v in v_obsts_dyn]
+    oa = [np.array(a, dtype=float) for a in a_obsts_dyn]
+    qs, qds = [], []
+    for _ in range(H):
+        qd = planner.solve(q, qd, x_obsts_dynamic=ox, xdot_obsts_dynamic=ov, xddot_obsts_dynamic=oa,
+                           radius_obsts_dynamic=list(radius_obsts_dyn), **params)          # FPC:430 (action = velocity)
+        q = q + dt * qd                                                                   # FPC:440-446
+        ox = [x + dt * v for x, v in zip(ox, ov)]                                         # FPC:448-453
+        qs.append(q.copy())
+        qds.append(qd.copy())
+    avg = sum(float(np.sum(v ** 2)) for v in qds) / (H * 7)                               # FPC:276-288
+    return np.array(qs), np.array(qds), avg
+
+
+def hand_estimate(q, qdot, mount, T=0.2):
+    """RF-CV goal estimate x_ee + 20 * 0.01 * v_ee with v_ee = J qdot (example_pandas_cartesian.py:355-357)."""
+    x, v, _, _ = panda_link_kinematics(q, qdot, mount, 8)
+    return x + T * v

@@ -159,7 +159,64 @@ def rollout():
     np.savez(os.path.join(OUT, "panda_rollout.npz"), mounts=np.stack(MOUNTS[:2]), **out)
 
 
+REF_MOUNTS = [np.eye(4) for _ in range(3)]          # parameters_manipulators.py:101-105,138-150 (N = 3)
+for _i, (_p, _yaw) in enumerate((([0.0, 0.0, 0.65], 0.0), ([1.0, 0.0, 0.65], math.pi), ([0.7, 0.6, 0.65], math.pi))):
+    REF_MOUNTS[_i][:2, :2] = [[math.cos(_yaw), -math.sin(_yaw)], [math.sin(_yaw), math.cos(_yaw)]]
+    REF_MOUNTS[_i][:3, 3] = _p
+REF_POS0_3 = np.array([[1.13793529, -0.3227085, -0.02767777, -2.2204281, -0.00917029, 1.88612235, 0.78536134],
+                       [1.131, 0.20, 0.12, -1.65, -0.0, 1.86, math.pi / 4],
+                       [-0.46609715, -0.25025564, -0.40425878, -2.0966941, -0.10682593, 1.84917516, 0.37170524]])  # PM:111-115
+REF_GOALS_3 = np.array([[0.25, 0.6, 1.15], [0.8, -0.5, 1.15], [0.4, 0.5, 0.95]])                                  # PM:130-132
+
+
+def rollout_c4(H=30):
+    """BASELINE config 4: 3-Panda RF-CV H=30 coupled joint-space rollout on the reference's own N = 3 cell (mounts, start
+    configurations and start goals of parameters_manipulators); robot 1 rolls out towards the goal ESTIMATED from its
+    hand, x_ee + 0.2 v_ee (EXJ:346-348 with the Cartesian driver's proper velocity, EXC:355-357).  Average velocities
+    and the last state only."""
+    rng = np.random.default_rng(17)
+    planners = [ao.Planner(mount=REF_MOUNTS[i], n_dynamic=16) for i in range(3)]
+    q0 = [REF_POS0_3[i] + rng.uniform(-0.05, 0.05, 7) for i in range(3)]
+    qd0 = [rng.uniform(-0.3, 0.3, 7) for _ in range(3)]
+    g0 = [REF_GOALS_3[i].copy() for i in range(3)]
+    g_est = ao.hand_estimate(q0[1], qd0[1], REF_MOUNTS[1])
+    params = [goal_kwargs(g_est if i == 1 else g0[i]) for i in range(3)]
+    qs, qds, avg = ao.rollout_jointspace(planners, q0, qd0, params, H=H, dynamic=True)
+    np.savez(os.path.join(OUT, "panda_rollout_c4.npz"), mounts=np.stack(REF_MOUNTS), q0=np.array(q0), qd0=np.array(qd0),
+             g0=np.array(g0), estimated_goal_1=g_est, estimate_mask=np.array(0b010), horizon=np.array(H),
+             avg=avg, q_last=qs[:, -1], qd_last=qds[:, -1])
+    print("rollout C4", avg)
+
+
+def rollout_cartesian(H=5):
+    """FabricsRollouts (forward_planner_Cartesian.py:347-563) for robot 0 and robot 1 of the reference's 2-robot cell:
+    the other robot's 8 link-origin spheres as constant-velocity obstacles (n_obst_per_link = 1, EXC:184), zero
+    obstacle accelerations (FPC:33), robot 1 with the RF-CV estimated goal."""
+    rng = np.random.default_rng(19)
+    mounts = REF_MOUNTS[:2]
+    q0 = [POS0 + rng.uniform(-0.15, 0.15, 7) for _ in range(2)]
+    qd0 = [rng.uniform(-0.4, 0.4, 7) for _ in range(2)]
+    g0 = [np.array([0.2, 0.6, 1.15]), np.array([0.8, -0.6, 1.15])]
+    out = dict(mounts=np.stack(mounts), q0=np.array(q0), qd0=np.array(qd0), g0=np.array(g0), horizon=np.array(H))
+    for i in range(2):
+        j = 1 - i
+        kin = [ao.panda_link_kinematics(q0[j], qd0[j], mounts[j], link) for link in range(1, 9)]
+        ox, ov = np.array([k[0] for k in kin]), np.array([k[1] for k in kin])
+        goal = ao.hand_estimate(q0[i], qd0[i], mounts[i]) if i == 1 else g0[i]
+        P = ao.Planner(mount=mounts[i], n_dynamic=8)
+        qs, qds, avg = ao.rollout_cartesian(P, q0[i], qd0[i], goal_kwargs(goal), ox, ov, np.zeros((8, 3)), [0.08] * 8, H)
+        out.update({f"r{i}_ox": ox, f"r{i}_ov": ov, f"r{i}_goal": goal, f"r{i}_q": qs, f"r{i}_qd": qds, f"r{i}_avg": np.array(avg)})
+        print("cartesian rollout robot", i, avg)
+    np.savez(os.path.join(OUT, "panda_cartesian.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                  # e.g. `make_golden.py rollout_c4 rollout_cartesian`: only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    rollout_c4()
+    rollout_cartesian()
     kinematics()
     planar_actions()
     panda_actions()

@@ -13,6 +13,8 @@ and writes data only (no reference source) to
     tests/golden/reference_panda_actions.npz     action [cases,7]        planner.compute_action(**kwargs)
     tests/golden/reference_planar_actions.npz    action [cases,3]
     tests/golden/reference_panda_rollout.npz     {dyn,stat}_{q,qd}[2,H,7], {dyn,stat}_avg[2]
+    tests/golden/reference_panda_rollout_c4.npz  avg[3] (+ q_last, qd_last [3,7])   BASELINE config 4: 3-Panda RF-CV H=30
+    tests/golden/reference_panda_cartesian.npz   r{0,1}_{q,qd}[H,7], r{0,1}_avg      FabricsRollouts (Cartesian variant)
 As soon as those files exist, tests/test_reference_pin.py (CPU: the oracle; -m gpu: the HIP kernels) compares against
 them instead of skipping, and tests/reconcile_constants.py fits the recalled constants of mrf_config to them.
 
@@ -21,6 +23,12 @@ The planners are built call by call as the reference's drivers build them:
     rollouts     examples/example_pandas_Jointspace.py:172-193 (define_rollout_planners), :354-375 (inputs_action),
                  multi_robot_fabrics/fabrics_planner/forward_planner_Jointspace.py:298-423
     point robot  examples/example_pointmasses_static.py:102-129 (set_planner_point), kwargs of :191-199
+    config 4     as "rollouts" with parameters_manipulators(nr_robots=3), N_HORIZON=30 and robot 1's goal replaced by the
+                 RF-CV estimate x_ee + 20*0.01*v_ee (EXJ:346-348) with v_ee = J qdot from
+                 UtilsKinematics.define_symbolic_endeffector / compute_endeffector (utils.py:120-136, utils_apply_fk.py:35-43)
+    Cartesian    examples/example_pandas_cartesian.py:160-192 (define_rollout_planners): FabricsRollouts +
+                 symbolic_forward_fabrics + preset_radii_obsts_dyn + define_arguments_numerical + rollouts_numerical /
+                 get_velocity_rollouts (forward_planner_Cartesian.py:347-563)
 The only liberty: the mount transform T_0 and the obstacle counts come from the golden case instead of from
 parameters_manipulators (set_mount_transformation / set_components take them as plain arguments anyway).
 """
@@ -184,6 +192,99 @@ def rollouts(mods, urdf):
     np.savez(os.path.join(HERE, "reference_panda_rollout.npz"), **out)
 
 
+def rollout_c4(mods, urdf):
+    """BASELINE config 4 through the reference's ForwardFabricsPlanner with three robots."""
+    import examples.parameters_manipulators as parameters_manipulators
+    from multi_robot_fabrics.fabrics_planner.forward_planner_Jointspace import ForwardFabricsPlanner
+    from multi_robot_fabrics.utils.utils import UtilsKinematics
+    from multi_robot_fabrics.utils.utils_apply_fk import compute_endeffector
+    g = np.load(os.path.join(HERE, "panda_rollout_c4.npz"))
+    N, H = 3, int(g["horizon"])
+    params = parameters_manipulators.manipulator_parameters(nr_robots=N)
+    params.define_settings(ROLLOUT_FABRICS=True, ROLLOUTS_PLOTTING=False, STATIC_OR_DYN_FABRICS=1, RESOLVE_DEADLOCKS=True,
+                           ESTIMATE_GOAL=True, N_HORIZON=H)
+    assert np.allclose(np.array(params.mount_transform, dtype=float), g["mounts"]), "fixture mounts != parameters_manipulators"
+    planners, goal_structs = [], []
+    for i in range(N):
+        p, gs = set_planner_panda(mods, urdf, params.mount_transform[i], nr_obst=params.nr_obsts[i],
+                                  nr_obst_dyn=params.nr_obsts_dyn[i], collision_links_nr=params.collision_links_nrs[i])
+        planners.append(p)
+        goal_structs.append(gs)
+    kin = UtilsKinematics()
+    fk_dict = kin.define_forward_kinematics(planners=planners, collision_links_nrs=params.collision_links_nrs,
+                                            collision_links=params.collision_links)
+    fk_endeff = kin.define_symbolic_endeffector(planners)
+    q0, qd0 = [g["q0"][i] for i in range(N)], [g["qd0"][i] for i in range(N)]
+    x_ee, v_ee = compute_endeffector(q0, qd0, fk_endeff, nr_robots=N)
+    goals = [g["g0"][i] for i in range(N)]
+    goals[1] = x_ee[1] + 20 * 0.01 * v_ee[1]                                     # EXJ:346-348 / EXC:355-357
+    print("estimated goal of robot 1:", goals[1], "(fixture:", g["estimated_goal_1"], ")")
+    fwd = ForwardFabricsPlanner(params=params, planners=planners, N_steps=10, fk_dict=fk_dict, goal_struct_robots=goal_structs)
+    fwd.forward_multi_fabrics_symbolic()
+    inputs_action = {"q_robots": q0, "q_dot_robots": qd0, "x_obsts": [[] * N], "x_goals0": goals,
+                     "x_goals1": [np.array([0.107, 0.0, 0.0])] * N, "x_goals2": [np.array([math.pi / 4])] * N,
+                     "weight_goals0": [2.0] * N, "weight_goals1": [20.0] * N, "weight_goals2": [1.0] * N,
+                     "constraints": [np.array([0, 0, 1, -params.z_table])] * N}
+    avg = fwd.get_velocity_rollouts(inputs_action=inputs_action)
+    out = {"avg": np.array([float(np.asarray(a).reshape(-1)[0]) for a in avg]), "estimated_goal_1": np.asarray(goals[1], dtype=float)}
+    print("rollout C4 avg", out["avg"])
+    try:
+        # rollouts_numerical is written for two robots (its result dictionaries hold robot_0 / robot_1 only, FPJ:346-348):
+        # the last state of all three comes from the per-robot functions it wraps, fed the same positional list
+        args = []
+        for i in range(N):
+            args.append(fwd.rotation_matrices_pandas[i])
+            args += [inputs_action["constraints"][i]] * fwd.nr_constraints[i]
+            args += [q0[i], qd0[i]]
+            args += [inputs_action["weight_goals%d" % s][i] for s in range(fwd.nr_subgoals[i])]
+            args += [inputs_action["x_goals%d" % s][i] for s in range(fwd.nr_subgoals[i])]
+            args += list(fwd.r_robots_args[i])
+            args += list(fwd.r_dyns_obsts[0 if i else 1])
+        out["q_last"] = np.stack([np.asarray(list(fwd.q_N_fun[i](*args))[-1].full()).reshape(-1) for i in range(N)])
+        out["qd_last"] = np.stack([np.asarray(list(fwd.q_dot_N_fun[i](*args))[-1].full()).reshape(-1) for i in range(N)])
+    except Exception as e:  # noqa: BLE001
+        print("last state not recorded (%s); the average velocities pin the rollout" % e)
+    np.savez(os.path.join(HERE, "reference_panda_rollout_c4.npz"), **out)
+
+
+def cartesian(mods, urdf):
+    """FabricsRollouts exactly as example_pandas_cartesian.py:160-192 builds it, on the inputs of panda_cartesian.npz."""
+    import examples.parameters_manipulators as parameters_manipulators
+    from multi_robot_fabrics.fabrics_planner.forward_planner_Cartesian import FabricsRollouts
+    g = np.load(os.path.join(HERE, "panda_cartesian.npz"))
+    H = int(g["horizon"])
+    params = parameters_manipulators.manipulator_parameters(nr_robots=2, n_obst_per_link=1)
+    params.define_settings(ROLLOUT_FABRICS=True, ROLLOUTS_PLOTTING=True, STATIC_OR_DYN_FABRICS=1, RESOLVE_DEADLOCKS=True,
+                           ESTIMATE_GOAL=True, N_HORIZON=H, n_obst_per_link=1)
+    assert np.allclose(np.array(params.mount_transform, dtype=float), g["mounts"])
+    out = {}
+    for i in range(2):
+        planner, goal_struct = set_planner_panda(mods, urdf, params.mount_transform[i], nr_obst=0,
+                                                 nr_obst_dyn=params.nr_obsts_dyn_all[i],
+                                                 collision_links_nr=params.collision_links_nrs[i])
+        v_obsts_dyn = [np.zeros((3,))] * params.nr_obsts_dyn_all[0]
+        fp = FabricsRollouts(N=H, dt=params.dt, nx=params.dof[i] * 2, nu=params.dof[i], dof=params.dof[i],
+                             nr_obsts=params.nr_obsts[i], bool_ring=False, nr_obsts_dyn=params.nr_obsts_dyn_all[i],
+                             v_obsts_dyn=v_obsts_dyn, fabrics_mode=params.fabrics_mode,
+                             collision_links_nrs=params.collision_links_nrs[i], nr_constraints=params.nr_constraints[i],
+                             radius_sphere=params.radius_sphere, constraints=params.constraints[i],
+                             nr_goals=len(goal_struct._config))
+        fp.symbolic_forward_fabrics(planner=planner, goal_struct=goal_struct)
+        fp.preset_radii_obsts_dyn(radii_obst_dyn=params.r_dyns_obsts[i])
+        weight_goals = {"subgoal0": 2.0, "subgoal1": 20.0, "subgoal2": 1.0}
+        x_goals = {"subgoal0": g["r%d_goal" % i], "subgoal1": np.array([0.107, 0.0, 0.0]), "subgoal2": np.array([math.pi / 4])}
+        arguments = fp.define_arguments_numerical(q_robot=g["q0"][i], q_dot_robot=g["qd0"][i], constraints=params.constraints[i],
+                                                  weight_goals=weight_goals, x_goals=x_goals, x_obsts=[],
+                                                  x_obsts_dyn=list(g["r%d_ox" % i]), v_obsts_dyn=list(g["r%d_ov" % i]))
+        q_N, q_dot_N, _ = fp.rollouts_numerical(arguments)                       # each [7, H] (FPC:538-559)
+        avg = fp.get_velocity_rollouts(arguments)
+        out["r%d_q" % i] = np.asarray(q_N, dtype=float).reshape(7, H).T
+        out["r%d_qd" % i] = np.asarray(q_dot_N, dtype=float).reshape(7, H).T
+        out["r%d_avg" % i] = np.array(float(np.asarray(avg.full() if hasattr(avg, "full") else avg).reshape(-1)[0]))
+        print("cartesian rollout robot", i, out["r%d_avg" % i])
+    np.savez(os.path.join(HERE, "reference_panda_cartesian.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("MRF_REFERENCE", "/root/reference"),
@@ -208,7 +309,9 @@ def main():
     panda_actions(mods, urdf)
     planar_actions(mods, ref_root)
     rollouts(mods, urdf)
-    print("wrote tests/golden/reference_{panda_actions,planar_actions,panda_rollout}.npz -- "
+    rollout_c4(mods, urdf)
+    cartesian(mods, urdf)
+    print("wrote tests/golden/reference_{panda_actions,planar_actions,panda_rollout,panda_rollout_c4,panda_cartesian}.npz -- "
           "now run: python -m pytest tests/test_reference_pin.py   and   python tests/reconcile_constants.py")
 
 

@@ -21,6 +21,25 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
+def build_native(out_dir):
+    """The same source compiled -march=native ON THIS HOST into out_dir (bench.py's cpu_baseline leg on the timed node);
+    returns the path, or None when there is no compiler / the build fails."""
+    out = os.path.join(out_dir, "libmrf_oracle.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "MARCH=native", "OUT=" + out], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return out if os.path.exists(out) else None
+
+
+def use_library(path):
+    """Switch the binding to another build of the oracle (same exports)."""
+    global _lib
+    _lib = C.CDLL(path)
+    return _lib
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -6,8 +6,14 @@
 Everything inside compute_action that the survey could only recall from the un-vendored `fabrics` package is a named
 field of mrf_config.  This script fits those fields to the reference's own outputs through the float64 oracle and
 prints, per field, default -> fitted value, the relative change, and whether the vectors can identify it at all:
-  * discrete conventions are enumerated: jdot_sign in {-1,+1}, plane_abs in {0,1}, zero_small_action in {0,1}, and the
-    two recalled candidates for the library's plane / limit Finsler strings;
+  * discrete conventions are enumerated: jdot_sign in {-1,+1}, plane_abs in {0,1}, zero_small_action in {0,1}, the
+    two recalled candidates for the library's plane / limit Finsler strings, and the attractor metric M = 2A (the
+    Hessian of L = xdot^T A xdot, the build's default) against M = A;
+  * composition conventions that are not fields of mrf_config are diagnosed on the single-step Panda cases from the
+    oracle's pulled specs (composition_variants below): eps applied at EVERY inverse, including the execution-energy
+    stage M_e = I (a factor 1/(1+eps) on h_g and h_f -- an O(1e-6) relative effect, i.e. exactly the pin test's
+    tolerance: a first-contact miss of that size is this convention, not a wrong constant), eps missing from the
+    energization denominators, and the unregularised inverse;
   * continuous constants are fitted by least squares (scipy) on multiplicative factors, starting from the defaults:
     base_mass, eps, attractor (k, alpha, mu, ml, a), damper beta (a, r, b, s) and eta (a, s), and the k of the
     limit-geometry, limit-Finsler and plane-Finsler strings.
@@ -54,7 +60,7 @@ def evaluate(theta, names, base, discrete, want):
         if n.endswith(".k"):
             leaf_k[n[:-2]] = base[n] * t
         else:
-            const[n] = base[n] * t
+            const[n] = base[n] * t * discrete.get("scale", {}).get(n, 1.0)
 
     def apply(cfg):
         from multi_robot_fabrics_amd import config
@@ -86,12 +92,60 @@ def evaluate(theta, names, base, discrete, want):
     return np.concatenate(res)
 
 
+def compose(cfg, Mg, fg, Mf, ff, qd, dist_goal0, h_scale=1.0, eps_inv=None, eps_den=None):
+    """SURVEY Appendix A.3 in numpy from pulled specs (the oracle's mrfo_specs), with the composition conventions
+    as switches: h = h_scale * (M + eps_inv I)^-1 f, alpha = -qd.h / (qd.qd + eps_den)."""
+    eps_inv = cfg.eps if eps_inv is None else eps_inv
+    eps_den = cfg.eps if eps_den is None else eps_den
+    n = len(qd)
+    hg = h_scale * np.linalg.solve(Mg + eps_inv * np.identity(n), fg)
+    hf = h_scale * np.linalg.solve(Mf + eps_inv * np.identity(n), ff)
+    qq = float(qd @ qd)
+    den = qq + eps_den if qq + eps_den > 0 else 1.0          # qdot = 0 without eps: the numerators are zero too
+    alpha_g, alpha_f = -float(qd @ hg) / den, -float(qd @ hf) / den
+    eta = 0.5 * (np.tanh(-cfg.eta_a * qq - cfg.eta_s) + 1.0)
+    a_ex = eta * alpha_g + (1.0 - eta) * alpha_f
+    beta = 0.5 * (np.tanh(-cfg.beta_a * (dist_goal0 - cfg.beta_r)) + 1.0) * cfg.beta_b + cfg.beta_s + max(0.0, alpha_g - a_ex)
+    qdd = -hf - (a_ex + beta) * qd
+    return qd + cfg.dt * qdd                         # mode 'vel' (EXJ:133)
+
+
+def composition_variants(want_actions):
+    """Max relative residual of the Panda single-step cases (goal cases only) under each composition convention."""
+    cases = [c for c in rc.panda_action_cases() if c[0] != "nogoal"]
+    idx = [i for i, c in enumerate(rc.panda_action_cases()) if c[0] != "nogoal"]
+    variants = {"as built: eps in both inverses and both denominators": {},
+                "eps at every stage incl. M_e = I: h / (1 + eps)": {"h_scale": "1/(1+eps)"},
+                "no eps in the energization denominators": {"eps_den": 0.0},
+                "unregularised inverse (eps only in the denominators)": {"eps_inv": 0.0}}
+    out = {}
+    for label, kw in variants.items():
+        worst = 0.0
+        for i, (kind, cfg, q, qd, prm, ox, ov, oa, orad, ns) in zip(idx, cases):
+            Mg, fg, Mf, ff = oracle_lib.specs(cfg, 0, q[:, 0], qd[:, 0], prm[:, 0], ox[:, :, 0], ov[:, :, 0], oa[:, :, 0],
+                                              orad[:, 0], n_static=ns)
+            c8 = cfg.copy()
+            from multi_robot_fabrics_amd import config
+            config.set_spheres(c8, list(range(1, 9)))
+            hand = oracle_lib.fk_spheres(c8, q, qd)[0][7, :, 0]
+            args = {k: (1.0 / (1.0 + cfg.eps) if v == "1/(1+eps)" else v) for k, v in kw.items()}
+            got = compose(cfg, Mg, fg, Mf, ff, qd[:, 0], float(np.linalg.norm(hand - prm[0:3, 0])), **args)
+            worst = max(worst, float(np.abs(got - want_actions[i]).max() / max(1e-300, np.abs(want_actions[i]).max())))
+        out[label] = worst
+    return out
+
+
 def main():
     want = {}
     for kind in ("panda_actions", "planar_actions", "panda_rollout"):
         if rc.have(kind):
             f = np.load(rc.FILES[kind])
             want[kind] = f["action"] if kind.endswith("actions") else {k: f[k] for k in f.files}
+    if "--self-check" in sys.argv:      # no reference files needed: the numpy composition reproduces the oracle's actions
+        got = rc.oracle_actions(oracle_lib, rc.panda_action_cases())
+        for label, err in composition_variants(got).items():
+            print(f"  {err:10.3e}  {label}")
+        return 0
     if not want:
         print(rc.HOW)
         return 2
@@ -100,13 +154,22 @@ def main():
     names = CONT + [n + ".k" for n in LEAF_K]
     scale = max(np.abs(v).max() if not isinstance(v, dict) else max(np.abs(x).max() for x in v.values()) for v in want.values())
     combos = []
-    for jsign, pabs, zsa, (pf_name, pf), (lf_name, lf) in itertools.product(
-            (-1.0, 1.0), (1, 0), (1, 0), FINSLER_CANDIDATES.items(), FINSLER_CANDIDATES.items()):
-        discrete = {"fields": {"jdot_sign": jsign, "plane_abs": pabs, "zero_small_action": zsa},
+    for jsign, pabs, zsa, (pf_name, pf), (lf_name, lf), attr_m in itertools.product(
+            (-1.0, 1.0), (1, 0), (1, 0), FINSLER_CANDIDATES.items(), FINSLER_CANDIDATES.items(), ("2A", "A")):
+        half = 0.5 if attr_m == "A" else 1.0            # M = A: the attractor metric without the Hessian's factor 2
+        discrete = {"fields": {"jdot_sign": jsign, "plane_abs": pabs, "zero_small_action": zsa,
+                               "attr_mu": base["attr_mu"] * half, "attr_ml": base["attr_ml"] * half},
+                    "scale": {"attr_mu": half, "attr_ml": half},
                     "strings": {"finsler_plane_constraint": pf, "limit_finsler": lf},
-                    "label": f"jdot_sign={jsign:+.0f} plane_abs={pabs} zero_small_action={zsa} plane_finsler={pf_name} limit_finsler={lf_name}"}
+                    "label": f"jdot_sign={jsign:+.0f} plane_abs={pabs} zero_small_action={zsa} plane_finsler={pf_name} "
+                             f"limit_finsler={lf_name} attractor_M={attr_m}"}
         r0 = evaluate(np.ones(len(names)), names, base, discrete, want)
         combos.append([float(np.abs(r0).max() / scale), discrete, None])
+    if "panda_actions" in want:
+        print("composition conventions on the single-step Panda cases (max relative residual against the reference):")
+        for label, err in composition_variants(want["panda_actions"]).items():
+            print(f"  {err:10.3e}  {label}")
+        print()
     print("discrete conventions at the default constants (max relative residual; the first line is the build's default):")
     for err, d, _ in combos[:1] + sorted(combos[1:], key=lambda c: c[0])[:5]:
         print(f"  {err:10.3e}  {d['label']}")

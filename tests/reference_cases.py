@@ -9,9 +9,10 @@ from multi_robot_fabrics_amd import abi, config
 from test_oracle_golden import params_row
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FILES = {k: os.path.join(GOLD, f"reference_{k}.npz") for k in ("panda_actions", "planar_actions", "panda_rollout")}
+KINDS = ("panda_actions", "planar_actions", "panda_rollout", "panda_rollout_c4", "panda_cartesian")
+FILES = {k: os.path.join(GOLD, f"reference_{k}.npz") for k in KINDS}
 HOW = ("parity with the CasADi path is UNPINNED: tests/golden/reference_*.npz are absent.  Generate them where the "
-       "reference runs (python<3.10, fabrics==0.9.5): python tests/golden/make_reference_golden.py")
+       "reference runs (python 3.9 + tests/golden/reference_env.txt): python tests/golden/make_reference_golden.py")
 
 
 def have(kind):
@@ -69,6 +70,45 @@ def rollout_cases(constants=None):
         apply_constants(cfg, constants)
         prm = np.stack([params_row(g[f"{name}_g0"][i], [0.08] * 6) for i in range(2)], axis=1)
         out.append((name, cfg, g[f"{name}_q0"].T.copy(), g[f"{name}_qd0"].T.copy(), prm))
+    return out
+
+
+def c4_case(constants=None):
+    """BASELINE config 4 (3-Panda RF-CV H=30, panda_rollout_c4.npz) -> (cfg, q0[7,3], qd0, prm[29,3]).  Robot 1's goal
+    is estimated on the device / in the oracle (goal_estimate_mask = 0b010); the parameter row carries the start goal."""
+    g = np.load(os.path.join(GOLD, "panda_rollout_c4.npz"))
+    cfg = config.panda_config(n_robots=3, horizon=int(g["horizon"]), dynamic=1, mounts=list(g["mounts"]))
+    cfg.goal_estimate_mask = int(g["estimate_mask"])
+    apply_constants(cfg, constants)
+    prm = np.stack([params_row(g["g0"][i], [0.08] * 6) for i in range(3)], axis=1)
+    return cfg, g["q0"].T.copy(), g["qd0"].T.copy(), prm
+
+
+def cartesian_cases(constants=None):
+    """FabricsRollouts cases of panda_cartesian.npz -> list of (name, cfg, q0[7,1], qd0, prm[29,1], ox[8,3,1], ov, orad[8,1]).
+    The obstacle accelerations are zero (FPC:33): the mirrored class passes obst_a = NULL."""
+    g = np.load(os.path.join(GOLD, "panda_cartesian.npz"))
+    out = []
+    for i in range(2):
+        cfg = config.panda_config(n_robots=1, horizon=int(g["horizon"]), dynamic=1, mounts=[g["mounts"][i]])
+        apply_constants(cfg, constants)
+        prm = params_row(g[f"r{i}_goal"], [0.08] * 6)
+        out.append((f"r{i}", cfg, g["q0"][i][:, None].copy(), g["qd0"][i][:, None].copy(), prm[:, None],
+                    g[f"r{i}_ox"][:, :, None].copy(), g[f"r{i}_ov"][:, :, None].copy(), np.full((8, 1), 0.08)))
+    return out
+
+
+def oracle_c4(oracle, case):
+    cfg, q0, qd0, prm = case
+    avg, tq, tqd = oracle.rollout(cfg, q0, qd0, prm, traj=True)
+    return {"avg": avg, "q_last": tq[-1].T, "qd_last": tqd[-1].T}
+
+
+def oracle_cartesian(oracle, cases):
+    out = {}
+    for name, cfg, q0, qd0, prm, ox, ov, orad in cases:
+        avg, tq, tqd = oracle.rollout_cartesian(cfg, q0, qd0, prm, ox, ov, np.zeros_like(ox), orad, traj=True)
+        out[name + "_q"], out[name + "_qd"], out[name + "_avg"] = tq[:, :, 0], tqd[:, :, 0], avg[0]
     return out
 
 

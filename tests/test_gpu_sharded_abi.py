@@ -74,7 +74,7 @@ def test_comm_argument_errors():
 @pytest.mark.parametrize("n_robots,horizon,n_scen,table,dtype", [(2, 8, 50, "lo", "f64"), (3, 6, 45, "lo", "f64"),
                                                                   (3, 4, 30, "offsets", "f64"), (2, 6, 40, "lo", "f32")])
 def test_two_processes_one_gpu_peer_exchange(n_robots, horizon, n_scen, table, dtype):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000", MRF_PEER_DEVICE_SHARE="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "sharded_worker.py"), str(n_robots),
            str(horizon), str(n_scen), table, dtype]
@@ -93,7 +93,7 @@ def test_plain_c_consumer_two_processes_one_gpu():
     handles, mrf_comm_peer_open / _connect, mrf_rollout_sharded) -- a non-Python consumer of the ABI runs the north-star
     partitioning; each process checks its rows against the fused kernel."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000", MRF_PEER_DEVICE_SHARE="2")
     out = subprocess.run([os.path.join(ROOT, "examples", "sharded_rollout_c"), "150", "10"], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr[-2000:]

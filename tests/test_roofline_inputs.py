@@ -1,0 +1,44 @@
+"""bench.py's roofline inputs are derived, not copied: every entry of profiles/traffic.json that names
+a PMC summary as its `source` must equal what tools/make_traffic.py computes from that file --
+bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 and flops_per_unit = (2*FMA + MUL + ADD)/SQ_WAVES/H -- and carry the
+kernel-source hash the summary was taken with."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_traffic  # noqa: E402
+
+
+def test_traffic_json_equals_its_sources():
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        tj = json.load(f)
+    checked = 0
+    for key, rec in tj.items():
+        if key.startswith("_") or "kernel" not in rec:
+            continue                                   # round-1 record kept for history (hand-entered then)
+        m = re.fullmatch(r"rollout_(f64|f32)_N(\d+)_H(\d+)_B(\d+)", key)
+        assert m, key
+        with open(os.path.join(ROOT, rec["source"])) as f:
+            pmc = json.load(f)
+        kernel = make_traffic.pick(pmc, "k_rollout_panda<")
+        want = make_traffic.derive(pmc[kernel], int(m.group(3)), m.group(1))
+        assert rec["bytes_per_launch"] == want["bytes_per_launch"], key
+        assert rec["flops_per_unit"] == want["flops_per_unit"], key
+        assert rec["kernel_source_sha256"] == pmc.get("_meta", {}).get("kernel_source_sha256"), key
+        # the batch in the key is the batch the counters were taken at: grid = waves * 64 lanes, 64 // N scenarios per wave
+        N, B = int(m.group(2)), int(m.group(4))
+        assert int(pmc[kernel]["SQ_WAVES"]) == -(-B // (64 // N)), key
+        checked += 1
+    assert checked >= 1
+
+
+def test_kernel_source_hash_is_of_the_two_kernel_files():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("multi-robot-fabrics_amd/csrc/mrf_kernels.hip", "multi-robot-fabrics_amd/csrc/mrf_device.hpp"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    assert make_traffic.kernel_source_sha256() == h.hexdigest()

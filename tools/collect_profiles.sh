@@ -15,4 +15,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" 
   specs="$specs $name=$out/pmc_$name"
 done
 python3 $root/tools/summarize_prof.py $tag $out/stats $root/gpurun_out/profiles $specs > $out/summary.log 2>&1
+# bench.py's roofline inputs, derived from the summary just written (never copied by hand)
+python3 $root/tools/make_traffic.py $root/gpurun_out/profiles/${tag}_pmc.json rollout_${dt}_N3_H30_B$B --out $root/gpurun_out/profiles/${tag}_traffic.json >> $out/summary.log 2>&1
 tail -c 3000 $out/summary.log

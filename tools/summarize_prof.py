@@ -55,6 +55,10 @@ def main():
                 s[c] = sum(v) / len(v)
             s.setdefault("launches", {})[spec.split("=")[0]] = len(disp)
             s.setdefault("duration_us_under_pmc", {})[spec.split("=")[0]] = sum(disp.values()) / len(disp)
+    # which kernel sources these counters belong to (tools/make_traffic.py, bench.py "roofline_inputs_stale")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from make_traffic import kernel_source_sha256
+    summary["_meta"] = {"kernel_source_sha256": kernel_source_sha256(), "tag": tag}
     with open(os.path.join(out_dir, f"{tag}_pmc.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps(summary, indent=1, sort_keys=True)[:6000])
