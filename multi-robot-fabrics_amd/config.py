@@ -148,6 +148,15 @@ def sphere_offsets_per_link(n_obst_per_link):
     return links, offsets
 
 
+def c5_sphere_table():
+    """BASELINE.json configs[4] "20 collision spheres/robot": the simulator's 3-per-link table (24 spheres) with every
+    sixth entry dropped, so that every link keeps at least two -- in particular link 8 / the hand, the link that
+    actually meets the other robots.  Returns (links, offsets)."""
+    links, offs = sphere_offsets_per_link(3)
+    keep = [i for i in range(len(links)) if i % 6 != 5]
+    return [links[i] for i in keep], [offs[i] for i in keep]
+
+
 def panda_config(n_robots=2, horizon=10, dynamic=1, n_ego=6, scalar=abi.F64, mounts=None, **strings):
     """Reference Panda planner (set_planner_panda, EXJ:64-134) for n_robots robots per scenario."""
     if not 1 <= n_robots <= abi.MRF_MAX_ROBOTS:

@@ -67,7 +67,9 @@ constexpr bool kCartSingleWalk = true;
 #endif
 
 // obstacle loop over HBM arrays [n_obst][3][rows] (compute_action / Cartesian rollout); tk = elapsed obstacle time
-template <class CL, typename T>
+// ACC = false: the caller passes no obstacle accelerations (oa == NULL -- what the reference's drivers do,
+// FPC:33, EXJ:411): the three acceleration loads per obstacle and the n.a_o term of every leaf are compiled out.
+template <class CL, bool ACC = true, typename T>
 __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int64_t rows, int64_t r, int n_obst,
                                                       int n_static, const T* __restrict__ ox, const T* __restrict__ ov,
                                                       const T* __restrict__ oa, const T* __restrict__ orad, T tk,
@@ -93,34 +95,38 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
   // the fold, so that the fetch is the same ten loads for every obstacle (no divergent address arithmetic).
   const T* pv = ov ? ov : ox;
   const T* pa = oa ? oa : ox;
-  pipelined_pairs<T, 10>(
+  constexpr int NV = ACC ? 10 : 7;  // x[3], v[3], (a[3],) radius
+  pipelined_pairs<T, NV>(
       n_obst - m_first,
-      [&](int mi, T (&buf)[10]) {
+      [&](int mi, T (&buf)[NV]) {
         const int m = mi + m_first;
         const int64_t base = (int64_t)(m * 3) * rows + r;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           buf[c] = ox[base + c * rows];
           buf[3 + c] = pv[base + c * rows];
-          buf[6 + c] = pa[base + c * rows];
+          if constexpr (ACC) buf[6 + c] = pa[base + c * rows];
         }
-        buf[9] = orad[(int64_t)m * rows + r];
+        buf[NV - 1] = orad[(int64_t)m * rows + r];
       },
-      [&](int mi, T (&buf)[10]) {
+      [&](int mi, T (&buf)[NV]) {
         const int m = mi + m_first;
         const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
-        const bool has_v = ov && !is_static, has_a = oa && !is_static;
+        const bool has_v = ov && !is_static, has_a = ACC && oa && !is_static;
         T xo[3], vo[3], ao[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           vo[c] = has_v ? buf[3 + c] : T(0);
           xo[c] = buf[c] + tk * vo[c];  // Cartesian rollout: x += dt*v per step (FPC:448-453); tk = 0 otherwise
-          ao[c] = has_a ? buf[6 + c] : T(0);
+          if constexpr (ACC)
+            ao[c] = has_a ? buf[6 + c] : T(0);
+          else
+            ao[c] = T(0);
         }
 #ifdef MRF_OBST_NOFOLD  // development switch (tools/build_variant.sh): the obstacle stream alone, results meaningless
-        acc.b[0][0] += xo[0] + xo[1] + xo[2] + vo[0] + vo[1] + vo[2] + ao[0] + ao[1] + ao[2] + buf[9];
+        acc.b[0][0] += xo[0] + xo[1] + xo[2] + vo[0] + vo[1] + vo[2] + ao[0] + ao[1] + ao[2] + buf[NV - 1];
 #else
-        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[9], allow_planar && !is_static && cfg.obst_dim == 2, acc);
+        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], allow_planar && !is_static && cfg.obst_dim == 2, acc);
 #endif
       });
 #endif
@@ -130,57 +136,174 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
 // elapsed time changes, FPC:448-453).  The set does not fit on chip (16 obstacles = 82 KB per wave in f64), but a prefix
 // does: the first CART_RESIDENT<T> obstacles of every row are copied once into a per-wave LDS tile [m][10][64] and folded
 // from there in every step, the rest streams from HBM / the Infinity Cache as before.
-template <typename T>
-constexpr int CART_RESIDENT = 35840 / (640 * (int)sizeof(T));  // 7 (f64), 14 (f32): 35 KB, four waves per CU
+// An obstacle is 10 scalars per row (x, v, a, radius) -- 7 when no accelerations are passed (ACC = false: FPC:33 presets
+// them to zero and the example drivers never change that), so the 35 KB tile holds 7 (ACC) or 10 of a row's obstacles in
+// f64 (14 / 20 in f32).
+template <typename T, bool ACC>
+constexpr int CART_RESIDENT = 35840 / ((ACC ? 10 : 7) * 64 * (int)sizeof(T));
 
-template <typename T>
+template <bool ACC, typename T>
 __device__ __forceinline__ void stage_resident_obstacles(T* __restrict__ res, int lane, int nres, int64_t rows, int64_t r,
                                                          const T* __restrict__ ox, const T* __restrict__ ov,
                                                          const T* __restrict__ oa, const T* __restrict__ orad) {
+  constexpr int NV = ACC ? 10 : 7;
   const T* pv = ov ? ov : ox;  // missing arrays: any finite value, zeroed in the fold
   const T* pa = oa ? oa : ox;
 #pragma unroll 1
   for (int m = 0; m < nres; ++m) {
     const int64_t base = (int64_t)(m * 3) * rows + r;
-    T* dst = res + m * 640 + lane;
+    T* dst = res + m * (NV * 64) + lane;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       dst[c * 64] = ox[base + c * rows];
       dst[(3 + c) * 64] = pv[base + c * rows];
-      dst[(6 + c) * 64] = pa[base + c * rows];
+      if constexpr (ACC) dst[(6 + c) * 64] = pa[base + c * rows];
     }
-    dst[9 * 64] = orad[(int64_t)m * rows + r];
+    dst[(NV - 1) * 64] = orad[(int64_t)m * rows + r];
   }
 }
 
-template <class CL, typename T>
+template <class CL, bool ACC, typename T>
 __device__ __forceinline__ void obstacles_resident(const DevCfg<T>& cfg, const T* __restrict__ res, int lane, int nres,
                                                    int n_static, bool any_v, bool any_a, T tk, const EgoPts<T, NG>& E,
                                                    EgoAcc<T, NG>& acc) {
   typedef const __attribute__((address_space(3))) T* lds_ptr;
-  pipelined_pairs<T, 10>(
+  constexpr int NV = ACC ? 10 : 7;
+  pipelined_pairs<T, NV>(
       nres,
-      [&](int m, T (&buf)[10]) {
-        lds_ptr src = (lds_ptr)(res + m * 640 + lane);
+      [&](int m, T (&buf)[NV]) {
+        lds_ptr src = (lds_ptr)(res + m * (NV * 64) + lane);
 #pragma unroll
-        for (int c = 0; c < 10; ++c) buf[c] = src[c * 64];
+        for (int c = 0; c < NV; ++c) buf[c] = src[c * 64];
       },
-      [&](int m, T (&buf)[10]) {
+      [&](int m, T (&buf)[NV]) {
+        const bool is_static = m < n_static;
+        const bool has_v = any_v && !is_static, has_a = ACC && any_a && !is_static;
+        T xo[3], vo[3], ao[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vo[c] = has_v ? buf[3 + c] : T(0);
+          xo[c] = buf[c] + tk * vo[c];
+          if constexpr (ACC)
+            ao[c] = has_a ? buf[6 + c] : T(0);
+          else
+            ao[c] = T(0);
+        }
+        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
+      });
+}
+
+// One pipelined loop over ALL obstacles of a row: the first nres come from the resident LDS tile, the rest from the HBM
+// arrays (wave-uniform switch inside the fetch).  A single loop keeps one pair of ping-pong buffers and two inlined copies
+// of the five-point fold alive instead of two loops with four.
+template <class CL, bool ACC, typename T>
+__device__ __forceinline__ void obstacles_cart(const DevCfg<T>& cfg, const T* __restrict__ res, int lane, int nres,
+                                               int64_t rows, int64_t r, int n_obst, int n_static,
+                                               const T* __restrict__ ox, const T* __restrict__ ov,
+                                               const T* __restrict__ oa, const T* __restrict__ orad, T tk,
+                                               const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  constexpr int NV = ACC ? 10 : 7;
+  const T* pv = ov ? ov : ox;
+  const T* pa = oa ? oa : ox;
+  const bool any_v = ov != nullptr, any_a = ACC && oa != nullptr;
+  pipelined_pairs<T, NV>(
+      n_obst,
+      [&](int m, T (&buf)[NV]) {
+        if (m < nres) {
+          lds_ptr src = (lds_ptr)(res + m * (NV * 64) + lane);
+#pragma unroll
+          for (int c = 0; c < NV; ++c) buf[c] = src[c * 64];
+        } else {
+          const int64_t base = (int64_t)(m * 3) * rows + r;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            buf[c] = ox[base + c * rows];
+            buf[3 + c] = pv[base + c * rows];
+            if constexpr (ACC) buf[6 + c] = pa[base + c * rows];
+          }
+          buf[NV - 1] = orad[(int64_t)m * rows + r];
+        }
+      },
+      [&](int m, T (&buf)[NV]) {
         const bool is_static = m < n_static;
         const bool has_v = any_v && !is_static, has_a = any_a && !is_static;
         T xo[3], vo[3], ao[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           vo[c] = has_v ? buf[3 + c] : T(0);
-          xo[c] = buf[c] + tk * vo[c];
-          ao[c] = has_a ? buf[6 + c] : T(0);
+          xo[c] = buf[c] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
+          if constexpr (ACC)
+            ao[c] = has_a ? buf[6 + c] : T(0);
+          else
+            ao[c] = T(0);
         }
-        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[9], false, acc);
+        accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
       });
 }
 
+// Interleaved form: iteration k folds streamed obstacle k (HBM / Infinity Cache) and resident obstacle k (LDS).  The
+// load of streamed obstacle k+1 is issued BEFORE both folds, i.e. it has two folds (~2 200 cycles, ~1 us) to arrive
+// instead of one -- a single wave per SIMD has nothing else to hide that latency with -- at the price of one more
+// buffer (two streamed + one resident) and a register copy of the streamed buffer per iteration.
+template <class CL, bool ACC, typename T>
+__device__ __forceinline__ void obstacles_cart_interleaved(const DevCfg<T>& cfg, const T* __restrict__ res, int lane,
+                                                           int nres, int64_t rows, int64_t r, int n_obst, int n_static,
+                                                           const T* __restrict__ ox, const T* __restrict__ ov,
+                                                           const T* __restrict__ oa, const T* __restrict__ orad, T tk,
+                                                           const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  constexpr int NV = ACC ? 10 : 7;
+  const T* pv = ov ? ov : ox;
+  const T* pa = oa ? oa : ox;
+  const bool any_v = ov != nullptr, any_a = ACC && oa != nullptr;
+  const int nS = n_obst - nres, nR = nres, K = nS > nR ? nS : nR;
+  auto fetch_stream = [&](int k, T (&buf)[NV]) {
+    const int m = nres + k;
+    const int64_t base = (int64_t)(m * 3) * rows + r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      buf[c] = ox[base + c * rows];
+      buf[3 + c] = pv[base + c * rows];
+      if constexpr (ACC) buf[6 + c] = pa[base + c * rows];
+    }
+    buf[NV - 1] = orad[(int64_t)m * rows + r];
+  };
+  auto fetch_resident = [&](int k, T (&buf)[NV]) {
+    lds_ptr src = (lds_ptr)(res + k * (NV * 64) + lane);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) buf[c] = src[c * 64];
+  };
+  auto fold = [&](int m, T (&buf)[NV]) {
+    const bool is_static = m < n_static;
+    const bool has_v = any_v && !is_static, has_a = any_a && !is_static;
+    T xo[3], vo[3], ao[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      vo[c] = has_v ? buf[3 + c] : T(0);
+      xo[c] = buf[c] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
+      if constexpr (ACC)
+        ao[c] = has_a ? buf[6 + c] : T(0);
+      else
+        ao[c] = T(0);
+    }
+    accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
+  };
+  T Sa[NV], Sb[NV], Rb[NV];
+  if (nS > 0) fetch_stream(0, Sa);
+#pragma unroll 1
+  for (int k = 0; k < K; ++k) {
+    if (k + 1 < nS) fetch_stream(k + 1, Sb);
+    if (k < nR) fetch_resident(k, Rb);
+    if (k < nS) fold(nres + k, Sa);
+    if (k < nR) fold(k, Rb);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) Sa[c] = Sb[c];
+  }
+}
+
 // ---------------------------------------------------------------------------- compute_action
-template <typename T, class LS>
+template <typename T, class LS, bool ACC>
 __global__ __launch_bounds__(256) MRF_ATTR_ACTION void k_action_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                        const T* __restrict__ q, const T* __restrict__ qd,
                                                        const T* __restrict__ prm, int n_obst, int n_static,
@@ -197,7 +320,8 @@ __global__ __launch_bounds__(256) MRF_ATTR_ACTION void k_action_panda(const DevC
   panda_solve_row<LS, kActionSingleWalk>(
       cfg, cfg.mount[(int)(r % cfg.n_robots)], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-        obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E, acc);
+        obstacles_from_arrays<typename LS::Collision, ACC>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E,
+                                                           acc);
       },
       qdd, act);
 #pragma unroll
@@ -435,7 +559,20 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
                                                        T* __restrict__ traj_q, T* __restrict__ traj_qd) {
   __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
+#ifdef MRF_EXP_LDSCFG
+  // experiment (VERDICT r2 next-4 ii): the planner constants staged in LDS once per block, so that the step loop reads
+  // them with ds_read (counted, in-order lgkmcnt) instead of scalar loads behind s_waitcnt lgkmcnt(0)
+  __shared__ DevCfg<T> scfg;
+  {
+    const int* src = reinterpret_cast<const int*>(cfgp);
+    int* dst = reinterpret_cast<int*>(&scfg);
+    for (int w = threadIdx.x; w < (int)(sizeof(DevCfg<T>) / 4); w += 64) dst[w] = src[w];
+    __syncthreads();
+  }
+  const DevCfg<T>& cfg = scfg;
+#else
   const DevCfg<T>& cfg = *cfgp;
+#endif
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
   const int spw = 64 / N;  // scenarios per wave
@@ -882,7 +1019,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
 // ---------------------------------------------------------------------------- Cartesian rollout
 // RES: the first CART_RESIDENT<T> obstacles live in LDS for the whole rollout (one wave per block); RES = false is the
 // plain streaming form with 256-thread blocks (switch -DMRF_CART_STREAM_ONLY, A/B by tools/prof_kernels.py).
-template <typename T, class LS, bool RES>
+template <typename T, class LS, bool RES, bool ACC>
 __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
                                                              const T* __restrict__ prm, int n_obst, int n_static,
@@ -898,9 +1035,10 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
   load_state(rows, r, q0, qd0, R);
   PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
   const T* mount_own = cfg.mount[(int)(r % cfg.n_robots)];
-  __shared__ T res[RES ? CART_RESIDENT<T> * 640 : 1];
-  const int nres = RES ? (n_obst < CART_RESIDENT<T> ? n_obst : CART_RESIDENT<T>) : 0;
-  if constexpr (RES) stage_resident_obstacles(res, (int)threadIdx.x, nres, rows, r, ox0, ov, oa, orad);
+  constexpr int NRES = CART_RESIDENT<T, ACC>;
+  __shared__ T res[RES ? NRES * (ACC ? 10 : 7) * 64 : 1];
+  const int nres = RES ? (n_obst < NRES ? n_obst : NRES) : 0;
+  if constexpr (RES) stage_resident_obstacles<ACC>(res, (int)threadIdx.x, nres, rows, r, ox0, ov, oa, orad);
   T sumsq = T(0);
   T tk = T(0);  // elapsed obstacle time k*dt
   const int H = cfg.horizon;
@@ -910,11 +1048,32 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
     panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          if constexpr (RES)
-            obstacles_resident<typename LS::Collision>(cfg, res, (int)threadIdx.x, nres, n_static, ov != nullptr,
-                                                       oa != nullptr, tk, E, acc);
-          obstacles_from_arrays<typename LS::Collision>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
-                                                        nres);
+          // measured (tools/prof_kernels.py, H=30, M=16, f64): with accelerations the two-loop form is the faster one
+          // (3.91 ms against 4.07 ms), without them the single loop (3.81 ms against 3.95 ms)
+#if defined(MRF_CART_TWO_LOOPS)
+          constexpr bool two_loops = true;
+#elif defined(MRF_CART_ONE_LOOP)
+          constexpr bool two_loops = false;
+#else
+          constexpr bool two_loops = ACC;
+#endif
+          if constexpr (RES && two_loops) {
+            obstacles_resident<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, n_static, ov != nullptr,
+                                                            oa != nullptr, tk, E, acc);
+            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false,
+                                                               E, acc, nres);
+#ifdef MRF_CART_INTERLEAVED
+          } else if constexpr (RES) {
+            obstacles_cart_interleaved<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, rows, r, n_obst, n_static,
+                                                                    ox0, ov, oa, orad, tk, E, acc);
+#endif
+          } else if constexpr (RES) {
+            obstacles_cart<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, rows, r, n_obst, n_static, ox0, ov,
+                                                        oa, orad, tk, E, acc);
+          } else {
+            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false,
+                                                               E, acc, 0);
+          }
         },
         qdd, act);
     // system_step (FPC:77-92); cos q / sin q advance by the angle-sum formula while every |dq| of the wave is small
@@ -1416,9 +1575,14 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
-    return launch(h, mrf::k_action_panda<T, LS>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q,
-                  (const T*)qdot, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov,
-                  (const T*)oa, (const T*)orad, (T*)qddot_out, (T*)action_out);
+    auto go = [&](auto kernel) {
+      return launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q, (const T*)qdot,
+                    (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
+                    (const T*)orad, (T*)qddot_out, (T*)action_out);
+    };
+    // no obstacle accelerations (obst_a == NULL; the reference's drivers pass zeros, EXJ:411): 7 loads per obstacle
+    if (oa) return go(mrf::k_action_panda<T, LS, true>);
+    return go(mrf::k_action_panda<T, LS, false>);
   });
 }
 
@@ -1484,15 +1648,20 @@ int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const voi
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
+    auto go = [&](auto kernel, dim3 g, dim3 b) {
+      return launch(h, kernel, g, b, st, (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0, (const T*)qdot0,
+                    (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0, (const T*)ov, (const T*)oa,
+                    (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+    };
+    // oa == NULL (the reference's own use: zero obstacle accelerations, FPC:33) takes the instantiation without the
+    // acceleration loads, with 10 instead of 7 obstacles of a row resident in LDS (f64)
 #ifdef MRF_CART_STREAM_ONLY
-    return launch(h, mrf::k_rollout_cart_panda<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, rows,
-                  (const T*)q0, (const T*)qdot0, (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox0,
-                  (const T*)ov, (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+    if (oa) return go(mrf::k_rollout_cart_panda<T, LS, false, true>, grid, block);
+    return go(mrf::k_rollout_cart_panda<T, LS, false, false>, grid, block);
 #else
-    return launch(h, mrf::k_rollout_cart_panda<T, LS, true>, dim3((unsigned)((rows + 63) / 64)), dim3(64), st,
-                  (const mrf::DevCfg<T>*)h->dcfg, rows, (const T*)q0, (const T*)qdot0, (const T*)params, (int)n_obst,
-                  (int)n_obst_static, (const T*)ox0, (const T*)ov, (const T*)oa, (const T*)orad, (T*)avg_out, (T*)traj_q,
-                  (T*)traj_qd);
+    const dim3 g64((unsigned)((rows + 63) / 64)), b64(64);
+    if (oa) return go(mrf::k_rollout_cart_panda<T, LS, true, true>, g64, b64);
+    return go(mrf::k_rollout_cart_panda<T, LS, true, false>, g64, b64);
 #endif
   });
 }

@@ -312,8 +312,10 @@ class ParameterizedFabricPlanner:
         M = ox.shape[0]
         # host arrays in, host array out: one packed copy each way inside the library (mrf_compute_action_host)
         if M:
-            act = h.compute_action_host(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None], oa[:, :, None],
-                                        orad[:, None], n_static=ns)
+            # zero accelerations (what the reference's drivers pass, EXJ:411) select the kernel without the acceleration
+            # loads and the n.a_o term: obst_a = NULL means zeros (include/mrf.h)
+            act = h.compute_action_host(q[:, None], qd[:, None], prm[:, None], ox[:, :, None], ov[:, :, None],
+                                        oa[:, :, None] if oa.any() else None, orad[:, None], n_static=ns)
         else:
             act = h.compute_action_host(q[:, None], qd[:, None], prm[:, None])
         return act[:, 0].copy()

@@ -316,7 +316,9 @@ class FabricsRollouts:
         h = self._handle
         q, qd, prm, ox, ov, oa, orad = self._unpack(arguments)
         if ox.shape[0]:
-            obst = (ox[:, :, None], ov[:, :, None], oa[:, :, None], orad[:, None])
+            # FPC:33 presets the obstacle accelerations to zero and the drivers never change them: obst_a = NULL selects the
+            # rollout kernel that neither loads nor folds them and keeps 10 instead of 7 obstacles resident on chip
+            obst = (ox[:, :, None], ov[:, :, None], oa[:, :, None] if oa.any() else None, orad[:, None])
         else:
             obst = (None, None, None, None)
         return h.rollout_cartesian_host(q[:, None], qd[:, None], prm[:, None], *obst, want_traj=traj, n_static=self.nr_obsts)

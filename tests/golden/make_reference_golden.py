@@ -40,6 +40,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE            # --out: where reference_*.npz are written (the inputs are always read from HERE)
 
 
 def need(mod):
@@ -117,7 +118,7 @@ def panda_actions(mods, urdf):
         action = np.asarray(planner.compute_action(**kw), dtype=float).reshape(-1)
         print("panda action", ci, kind, action)
         out.append(action)
-    np.savez(os.path.join(HERE, "reference_panda_actions.npz"), action=np.stack(out), kinds=g["kinds"])
+    np.savez(os.path.join(OUT, "reference_panda_actions.npz"), action=np.stack(out), kinds=g["kinds"])
 
 
 def planar_actions(mods, ref_root):
@@ -151,7 +152,7 @@ def planar_actions(mods, ref_root):
         action = np.asarray(planner.compute_action(**kw), dtype=float).reshape(-1)
         print("planar action", ci, action)
         out.append(action)
-    np.savez(os.path.join(HERE, "reference_planar_actions.npz"), action=np.stack(out))
+    np.savez(os.path.join(OUT, "reference_planar_actions.npz"), action=np.stack(out))
 
 
 def rollouts(mods, urdf):
@@ -189,7 +190,7 @@ def rollouts(mods, urdf):
         out[name + "_qd"] = np.stack([np.asarray(qdN["robot_%d" % i][0]).reshape(7, H).T for i in range(2)])
         out[name + "_avg"] = np.array([float(np.asarray(a).reshape(-1)[0]) for a in avg])
         print("rollout", name, out[name + "_avg"])
-    np.savez(os.path.join(HERE, "reference_panda_rollout.npz"), **out)
+    np.savez(os.path.join(OUT, "reference_panda_rollout.npz"), **out)
 
 
 def rollout_c4(mods, urdf):
@@ -244,7 +245,7 @@ def rollout_c4(mods, urdf):
         out["qd_last"] = np.stack([np.asarray(list(fwd.q_dot_N_fun[i](*args))[-1].full()).reshape(-1) for i in range(N)])
     except Exception as e:  # noqa: BLE001
         print("last state not recorded (%s); the average velocities pin the rollout" % e)
-    np.savez(os.path.join(HERE, "reference_panda_rollout_c4.npz"), **out)
+    np.savez(os.path.join(OUT, "reference_panda_rollout_c4.npz"), **out)
 
 
 def cartesian(mods, urdf):
@@ -282,14 +283,54 @@ def cartesian(mods, urdf):
         out["r%d_qd" % i] = np.asarray(q_dot_N, dtype=float).reshape(7, H).T
         out["r%d_avg" % i] = np.array(float(np.asarray(avg.full() if hasattr(avg, "full") else avg).reshape(-1)[0]))
         print("cartesian rollout robot", i, out["r%d_avg" % i])
-    np.savez(os.path.join(HERE, "reference_panda_cartesian.npz"), **out)
+    np.savez(os.path.join(OUT, "reference_panda_cartesian.npz"), **out)
+
+
+def mirrors_as_reference_modules(repo_root):
+    """--dry-run-with-mirrors: this build's mirror classes under the reference's import names, so that the recipe below runs
+    end to end on the GPU WITHOUT the reference stack.  It proves the recipe's plumbing (call sequence, keyword names,
+    result shapes, file keys) -- not parity: the files it writes come from this build and must never be committed as
+    reference_*.npz (main() refuses to write them next to the fixtures)."""
+    import types
+    sys.path.insert(0, repo_root)
+    from multi_robot_fabrics_amd import goals, kinematics, planner, rollouts
+
+    def module(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    module("casadi")
+    for pkg in ("fabrics", "fabrics.planner", "forwardkinematics", "forwardkinematics.urdfFks", "mpscenes", "mpscenes.goals",
+                "multi_robot_fabrics", "multi_robot_fabrics.fabrics_planner", "multi_robot_fabrics.utils"):
+        module(pkg, __path__=[])
+    module("fabrics.planner.parameterized_planner", ParameterizedFabricPlanner=planner.ParameterizedFabricPlanner)
+    module("forwardkinematics.urdfFks.generic_urdf_fk", GenericURDFFk=kinematics.GenericURDFFk)
+    module("mpscenes.goals.goal_composition", GoalComposition=goals.GoalComposition)
+    module("multi_robot_fabrics.fabrics_planner.forward_planner_Jointspace", ForwardFabricsPlanner=rollouts.ForwardFabricsPlanner)
+    module("multi_robot_fabrics.fabrics_planner.forward_planner_Cartesian", FabricsRollouts=rollouts.FabricsRollouts)
+    module("multi_robot_fabrics.utils.utils", UtilsKinematics=kinematics.UtilsKinematics)
+    module("multi_robot_fabrics.utils.utils_apply_fk", compute_endeffector=kinematics.compute_endeffector,
+           compute_x_obsts_dyn_0=kinematics.compute_x_obsts_dyn_0)
 
 
 def main():
+    global OUT
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=os.environ.get("MRF_REFERENCE", "/root/reference"),
                     help="checkout of tud-amr/multi-robot-fabrics (for its URDFs and its rollout classes)")
+    ap.add_argument("--out", default=HERE, help="directory for reference_*.npz (default: next to the fixtures)")
+    ap.add_argument("--dry-run-with-mirrors", action="store_true",
+                    help="run the recipe on this build's mirror classes (needs a GPU and --out elsewhere); plumbing check only")
     args = ap.parse_args()
+    OUT = os.path.abspath(args.out)
+    if args.dry_run_with_mirrors:
+        if os.path.samefile(OUT, HERE):
+            sys.exit("--dry-run-with-mirrors writes this build's OWN outputs: give --out a scratch directory")
+        repo_root = os.path.dirname(os.path.dirname(HERE))
+        args.reference = repo_root               # examples/simulation_environments/urdfs/*.urdf, examples.parameters_manipulators
+        mirrors_as_reference_modules(repo_root)
     ref_root = os.path.abspath(args.reference)
     urdf_path = os.path.join(ref_root, "examples", "simulation_environments", "urdfs", "panda_with_finger.urdf")
     if not os.path.exists(urdf_path):

@@ -246,7 +246,9 @@ def test_sharded_step_matches_fused_rollout(oracle, robot_first, robot_count, r1
 def test_properties_at_bench_size():
     """Size-independent properties on the full bench batch (no oracle: too slow at this size):
     obstacle-permutation invariance, static == dynamic with zero v/a, H=1 rollout == Euler step + compute_action."""
-    N, B = 3, 4096
+    N = 3
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 6 * cus * 4 * (64 // N)                            # bench.py's batch: 129 024 scenarios on a 256-CU MI355X
     cfg = config.panda_config(n_robots=N, horizon=1)
     batch = scenarios.panda_batch(cfg, B, seed=61)
     h = FabricHandle(cfg, 0)
@@ -338,8 +340,9 @@ def test_baseline_config_5_eight_pandas_h50(oracle, kernel):
     """BASELINE configs[4] at its full shape: 8 Pandas, RF-CV, H=50, 20 spheres per robot (140 obstacle spheres each)."""
     cfg = config.panda_config(n_robots=8, horizon=50)
     cfg.kernel_select = kernel
-    links, offs = config.sphere_offsets_per_link(3)
-    config.set_spheres(cfg, links[:20], offs[:20])
+    links, offs = config.c5_sphere_table()                  # 20 spheres, two of them on link 8 / the hand
+    assert len(links) == 20 and links.count(8) == 2 and all(links.count(l) >= 2 for l in range(1, 9))
+    config.set_spheres(cfg, links, offs)
     cfg.goal_estimate_mask = 0xFE
     batch = scenarios.panda_batch(cfg, 10, seed=91, x_min=0.3, q_spread=0.15)
     want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)

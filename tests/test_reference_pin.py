@@ -167,3 +167,35 @@ def test_composition_conventions_are_diagnosable(oracle):
     assert v[labels[0]] < 1e-10
     assert 1e-8 < v[labels[1]] < 1e-5        # eps at every stage: ~1e-6 relative, the size of TOL
     assert all(1e-9 < v[k] < 1e-4 for k in labels[2:])
+
+
+@pytest.mark.gpu
+def test_reference_recipe_dry_run_on_the_mirrors(tmp_path):
+    """tests/golden/make_reference_golden.py cannot run where the reference's wheels are missing -- but its plumbing
+    can: with this build's mirror classes standing in under the reference's import names (--dry-run-with-mirrors) the
+    whole recipe runs on the GPU, writes every reference_*.npz key the pin tests read, and -- because the mirrors are the
+    kernels -- reproduces the committed (autodiff) fixtures.  Not a parity statement: the day the real stack runs it,
+    the call sequence, keyword names, shapes and keys are already known to be right."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(rc.GOLD, "make_reference_golden.py")
+    out = subprocess.run([sys.executable, script, "--dry-run-with-mirrors", "--out", str(tmp_path)], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    refuse = subprocess.run([sys.executable, script, "--dry-run-with-mirrors"], capture_output=True, text=True, timeout=120)
+    assert refuse.returncode != 0 and "scratch directory" in (refuse.stderr + refuse.stdout)   # never next to the fixtures
+    got = {k: np.load(os.path.join(str(tmp_path), f"reference_{k}.npz")) for k in rc.KINDS}
+    g = np.load(rc.GOLD + "/panda_actions.npz")
+    for i, kind in enumerate(g["kinds"]):
+        assert rel(got["panda_actions"]["action"][i], g["action"][i]) < (1e-7 if kind in ("near", "nogoal") else 1e-9), kind
+    assert rel(got["planar_actions"]["action"], np.load(rc.GOLD + "/planar_actions.npz")["action"]) < 1e-9
+    gr = np.load(rc.GOLD + "/panda_rollout.npz")
+    for k in ("dyn_q", "dyn_qd", "dyn_avg", "stat_q", "stat_qd", "stat_avg"):
+        assert rel(got["panda_rollout"][k], gr[k]) < 1e-9, k
+    g4 = np.load(rc.GOLD + "/panda_rollout_c4.npz")
+    assert rel(got["panda_rollout_c4"]["avg"], g4["avg"]) < 1e-8
+    assert rel(got["panda_rollout_c4"]["estimated_goal_1"], g4["estimated_goal_1"]) < 1e-12
+    gc = np.load(rc.GOLD + "/panda_cartesian.npz")
+    for k in ("r0_q", "r0_qd", "r0_avg", "r1_q", "r1_qd", "r1_avg"):
+        assert rel(got["panda_cartesian"][k], gc[k]) < 1e-9, k

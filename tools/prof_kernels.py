@@ -56,6 +56,8 @@ ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, sa)
 report("k_fk_spheres_panda", timed(lambda: h.fk_spheres(q, qd)), rows, sb * (14 + 9 * S), "rows")
 report("k_action_panda (M=16 from HBM)", timed(lambda: h.compute_action(q, qd, prm, ox, ov, oa, orad)), rows,
        sb * (14 + 29 + 10 * M + 7), "rows")
+report("k_action_panda (M=16 from HBM, obst_a = NULL)", timed(lambda: h.compute_action(q, qd, prm, ox, ov, None, orad)), rows,
+       sb * (14 + 29 + 7 * M + 7), "rows")
 report("k_action_coupled", timed(lambda: h.compute_action_coupled(q, qd, prm)), rows, sb * (14 + 29 + 7), "rows")
 report("k_rollout_panda (H=30)", timed(lambda: h.rollout(q, qd, prm)), rows * H, sb * (28 + 9 * S * N) + sb * 23 / H,
        "rollout_steps")

@@ -15,6 +15,15 @@ import shutil
 import sys
 
 
+def short_name(k):
+    """Demangled kernel name without its argument list and with the leaf-policy set abbreviated, so that instantiations
+    that differ only in their trailing flags (LO, RES, ACC ...) keep distinct keys."""
+    k = k.split("(")[0]
+    k = k.replace("mrf::LeafSet<mrf::LeafPow<4, 4, 0, 0>, mrf::SLeaf<1, 0, 0, 1, 1>, mrf::SLeaf<0, 1, 0, 1, 1> >", "LS_reference")
+    k = k.replace("mrf::LeafSet<mrf::LeafGeneric, mrf::SLeafGeneric, mrf::SLeafGeneric>", "LS_generic")
+    return k.replace("void ", "")[:120]
+
+
 def find(d, suffix):
     hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
     return hits[0] if hits else None
@@ -41,7 +50,7 @@ def main():
                 continue
             gmax = max(int(r["Grid_Size"]) for r in rs)
             rs = [r for r in rs if int(r["Grid_Size"]) == gmax]
-            key = k[:96]
+            key = short_name(k)
             s = summary[key]
             s["grid_size"] = gmax
             s["vgpr"], s["agpr"], s["lds_bytes"], s["scratch_bytes"] = (
