@@ -96,3 +96,24 @@ def test_stuck_secondary_block_cannot_take_the_headline_with_it():
     # rank 0's own guard normally fires first; if the other rank's exit reaches it earlier, the block reports that instead
     err = r["robot_sharded"].get("error") or r["robot_sharded"]["peer"]["error"]
     assert err and ("timeout" in err or "Error" in err)
+
+
+def test_four_ranks_one_gpu_one_robot_per_rank_plus_a_replica():
+    """BASELINE config 4's layout on the 1/2/4/8 ladder: 3 Pandas on 4 ranks = a group of three ranks with ONE ROBOT EACH
+    (peer exchange every rollout step) + a group of one rank carrying all three robots on a third of the scenarios
+    (sharded.group_layout -> [3, 1]).  Four processes share the one GPU of the test box; every rank checks its rows against
+    the fused kernel."""
+    env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="8000")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--scenarios", "504",
+           "--shard", "robots", "--transport", "peer"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 4 and r["transport"] == "peer"
+    assert r["config"]["robot_groups"] == [3, 1] and r["config"]["scenarios_per_group"] == [504, 168]
+    assert r["config"]["robots_per_rank_all"] == [1, 1, 1, 3] and r["config"]["robots_per_rank"] == [1, 1, 1]
+    assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]            # MAX over all four ranks
+    assert abs(r["value"] - (504 + 168) * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
+    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 1 * 6 * 9 * 504 * 8

@@ -195,6 +195,32 @@ def test_rollout_cartesian(oracle, scalar):
         assert np.allclose(avg, want_avg, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("accel", ["zeros", "none", "given"])
+def test_rollout_cartesian_more_obstacles_than_resident(oracle, accel):
+    """16 obstacle spheres per row: more than the LDS-resident prefix (7 with accelerations, 10 without), so both the
+    resident and the streamed part of the obstacle loop fold.  obst_a = None (the reference's use, FPC:33) takes the
+    instantiation without acceleration loads and must equal the oracle with zero accelerations; nonzero accelerations
+    take the other one."""
+    cfg = config.panda_config(n_robots=3, horizon=6)
+    batch = scenarios.panda_batch(cfg, 70, seed=37, x_min=0.1)
+    ox, ov, oa, orad = _obstacles_from_other_robots(cfg, batch, oracle)
+    assert ox.shape[0] == 16
+    if accel != "given":
+        oa[:] = 0.0
+    want_avg, want_q, want_qd = oracle.rollout_cartesian(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad, traj=True)
+    h = FabricHandle(cfg, 0)
+    t = h.tensor
+    avg, tq, tqd = h.rollout_cartesian(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), t(ox), t(ov),
+                                       None if accel == "none" else t(oa), t(orad), want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL and relerr(tq.cpu().numpy(), want_q) < F64_RTOL
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+    # compute_action takes the same two instantiations
+    _, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    act = h.compute_action(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), t(ox), t(ov),
+                           None if accel == "none" else t(oa), t(orad))
+    assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
+
+
 def test_fk_spheres_with_offsets(oracle):
     cfg = config.panda_config(n_robots=3, horizon=1)
     links, offs = config.sphere_offsets_per_link(4)
