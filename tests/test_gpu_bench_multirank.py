@@ -117,3 +117,25 @@ def test_four_ranks_one_gpu_one_robot_per_rank_plus_a_replica():
     assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]            # MAX over all four ranks
     assert abs(r["value"] - (504 + 168) * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
     assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 1 * 6 * 9 * 504 * 8
+
+
+def test_eight_ranks_one_gpu_default_run_groups_3_3_2():
+    """What `python bench.py --gpus 8` does on an 8-GPU node, with the eight ranks sharing the one GPU of the test box: the
+    scenario-sharded headline over 8 ranks, then the robot-sharded block with 3 Pandas on 8 ranks = groups [3, 3, 2]
+    (two groups with one robot per rank, one group of two ranks carrying 2 + 1 robots on half the scenarios)."""
+    env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="20000")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--scenarios", "504"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["scenarios_per_gpu"] == 504
+    assert abs(r["value"] - 8 * 504 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
+    peer = r["robot_sharded"]["peer"]
+    assert "error" not in peer, peer
+    assert peer["config"]["robot_groups"] == [3, 3, 2] and peer["config"]["scenarios_per_group"] == [504, 504, 252]
+    assert peer["config"]["robots_per_rank_all"] == [1, 1, 1, 1, 1, 1, 2, 1]
+    assert peer["parity_vs_fused_kernel"]["ok"], peer["parity_vs_fused_kernel"]
