@@ -262,9 +262,10 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
                         void* stream);
 /* Waits for the stream of the last mrf_rollout_sharded and reports a timed-out exchange (MRF_E_LAUNCH) or MRF_OK. */
 int mrf_comm_status(mrf_handle* h);
-/* Clears a timed-out PEER exchange so that the communicator can be used again (the flags carry ever-growing sequence
- * numbers and need no clearing).  Call it on EVERY rank of the group, after the caller's own barrier: the ranks must
- * agree on the next mrf_rollout_sharded call.  A no-op for the RCCL transport. */
+/* Makes a communicator usable again after a timed-out PEER exchange: clears the error word and the flags in this rank's
+ * exchange buffer and restarts the sequence numbers.  Call it on EVERY rank of the group, BETWEEN two barriers of the
+ * caller's (no rank may still be inside, or already start, a mrf_rollout_sharded while another one resets); afterwards
+ * the ranks continue with the same sequence of calls again.  A no-op for the RCCL transport. */
 int mrf_comm_reset(mrf_handle* h);
 #define MRF_PEER_TIMEOUT_DEFAULT_MS 10000 /* bounded flag wait of the PEER kernel; override: env MRF_PEER_TIMEOUT_MS */
 /* env MRF_PEER_DEVICE_SHARE = k: k ranks of a group run on ONE device (single-GPU test setups); the PEER kernel then caps

@@ -668,8 +668,14 @@ int mrf_comm_reset(mrf_handle* h) {
   Comm* c = (Comm*)h->comm;
   if (!c) return fail(h, MRF_E_ARG, "no communicator");
   if (int rc = check_hip(h, hipStreamSynchronize(c->last_stream), "hipStreamSynchronize")) return rc;
-  if (c->transport == MRF_TRANSPORT_PEER)  // the flags carry ever-growing sequence numbers and need no clearing
-    return check_hip(h, hipMemset(c->local + c->off_err, 0, sizeof(int)), "hipMemset");
+  if (c->transport == MRF_TRANSPORT_PEER) {
+    // error word, the flags the peers raised in THIS rank's buffer, and the sequence counter: after the reset every rank
+    // starts from sequence 1 again, whatever number of rollouts each of them had issued before (a rank that missed a
+    // call is the usual reason for the timeout).  The caller's barriers on both sides keep peers from writing meanwhile.
+    if (int rc = check_hip(h, hipMemset(c->local + c->off_flags, 0, c->off_x - c->off_flags), "hipMemset")) return rc;
+    if (int rc = check_hip(h, hipDeviceSynchronize(), "hipDeviceSynchronize")) return rc;
+    c->seq = 1;
+  }
   return MRF_OK;
 }
 

@@ -98,3 +98,18 @@ def test_plain_c_consumer_two_processes_one_gpu():
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr[-2000:]
     assert out.stdout.count("rel err vs fused kernel") == 2, out.stdout
+
+
+def test_peer_timeout_is_loud_and_recoverable():
+    """A peer that skips a rollout: the waiting rank's exchange times out (bounded), its rollout leaves q / qdot alone and
+    returns NaN, mrf_comm_status reports it; mrf_comm_reset on every rank between two barriers makes the group usable
+    again although the ranks had issued different numbers of rollouts (tests/timeout_worker.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="400", MRF_PEER_DEVICE_SHARE="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "tests", "timeout_worker.py")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ranks = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["ranks"]
+    r0 = next(r for r in ranks if r["rank"] == 0)
+    assert r0["status_raised"] is True and r0["avg_all_nan"] and r0["state_untouched"], r0
+    assert all(r["err_after_reset"] < 1e-9 for r in ranks), ranks

@@ -1,0 +1,64 @@
+"""Worker of tests/test_gpu_sharded_abi.py::test_peer_timeout_is_loud_and_recoverable: two ranks share the GPU; rank 1
+SKIPS the first rollout, so rank 0's exchange times out.  Expected on rank 0: q / qdot untouched, NaN velocity signal,
+mrf_comm_status raises; after mrf_comm_reset on both ranks (between two barriers) the group works again."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from multi_robot_fabrics_amd import config, scenarios
+from multi_robot_fabrics_amd.runtime import FabricHandle, MrfError
+from multi_robot_fabrics_amd.sharded import ShardedRollout
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    N, H, B = 2, 5, 40
+    cfg = config.panda_config(n_robots=N, horizon=H)
+    batch = scenarios.panda_batch(cfg, B, seed=21)
+    sr = ShardedRollout(cfg, rank, world, device_index=0, transport="peer", max_scenarios=B)
+    h = sr.backend.h
+    rows = sr.own_rows(B).numpy()
+    q0, qd0, prm = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
+    report = {"rank": rank}
+    if rank == 0:                                     # the peer never publishes: bounded wait, loud result
+        q, qd = q0.clone(), qd0.clone()
+        avg = sr.rollout(q, qd, prm)
+        try:
+            h.comm_status()
+            report["status_raised"] = False
+        except MrfError as e:
+            report["status_raised"] = "timed out" in str(e)
+        report["avg_all_nan"] = bool(torch.isnan(avg).all())
+        report["state_untouched"] = bool(torch.equal(q, q0) and torch.equal(qd, qd0))
+    dist.barrier()
+    h.comm_reset()
+    dist.barrier()
+    ref = FabricHandle(cfg, 0)
+    want = ref.rollout(*(ref.tensor(batch[k]) for k in ("q", "qdot", "params")))[torch.as_tensor(rows, device="cuda")]
+    errs = []
+    for _ in range(2):
+        q, qd = q0.clone(), qd0.clone()
+        avg = sr.rollout(q, qd, prm)
+        h.comm_status()
+        errs.append(float((avg - want).abs().max() / want.abs().max()))
+    report["err_after_reset"] = max(errs)
+    out = [None] * world
+    dist.all_gather_object(out, report)
+    if rank == 0:
+        print(json.dumps({"ranks": out}))
+    dist.barrier()
+    h.comm_destroy()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
