@@ -325,6 +325,7 @@ def main():
                     help="run the recipe on this build's mirror classes (needs a GPU and --out elsewhere); plumbing check only")
     args = ap.parse_args()
     OUT = os.path.abspath(args.out)
+    os.makedirs(OUT, exist_ok=True)
     if args.dry_run_with_mirrors:
         if os.path.samefile(OUT, HERE):
             sys.exit("--dry-run-with-mirrors writes this build's OWN outputs: give --out a scratch directory")
