@@ -300,3 +300,20 @@ def test_plain_c_consumer_of_the_sharded_abi_builds():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
     assert os.path.exists(os.path.join(root, "examples", "sharded_rollout_c"))
+
+
+def test_bench_watchdog_fires_only_when_the_block_overruns():
+    """bench.run_guarded: the wall-clock guard around the robot-sharded block (no GPU needed: the module's GPU work is
+    under main())."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fired = []
+    assert bench.run_guarded(lambda: 7, None, lambda: fired.append("x")) == 7 and not fired      # no guard requested
+    assert bench.run_guarded(lambda: 8, 5.0, lambda: fired.append("x")) == 8
+    time.sleep(0.05)
+    assert not fired                                                                              # returned in time
+    assert bench.run_guarded(lambda: (time.sleep(0.3), 9)[1], 0.05, lambda: fired.append("late")) == 9
+    assert fired == ["late"]                                                                      # overran: guard fired once
