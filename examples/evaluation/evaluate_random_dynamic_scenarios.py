@@ -1,32 +1,29 @@
 #!/usr/bin/env python3
-"""The reference's examples/evaluation/evaluate_random_dynamic_scenarios.py: random pick-and-place scenes for two Pandas
-under the three methods it compares (:36-72)
+"""Random pick-and-place scenes for two Pandas under the three methods the reference compares
 
-    "dynamic"                      MRDF: compute_action against the other robot's moving spheres, no rollouts
-    "rollouts dynamic"             + Rollout Fabrics every control step and the deadlock logic on their velocity signal
-    "rollouts dynamic estimated"   + robot 1's goal is not communicated but estimated (RF-CV), deadlock logic off (:66-68)
+    "dynamic"                      multi-robot dynamic fabrics: every arm avoids the other arm's moving spheres, no rollouts
+    "rollouts dynamic"             + joint-space Rollout Fabrics every control step, deadlock logic on their velocity signal
+    "rollouts dynamic estimated"   + robot 1's goal is not communicated but estimated from its hand motion (RF-CV)
 
-with two ways to run them:
+`define_run_evaluations(n_steps=100, render=False, n_runs=1)` is the reference's entry point
+(examples/evaluation/evaluate_random_dynamic_scenarios.py) and reports its statistics -- time to success, collision
+episodes, minimum clearance, solver / step time, success rate; mean +- std per case, as a dictionary and a text table --
+but the n_runs random scenes of a case are not run one after the other: they are the `scenes` of ONE
+multi_robot_fabrics_amd.cell.PandaCell and advance together, one HIP graph launch per control step for all of them.
+`run_case` is the same thing for thousands of scenes with cubes spread over each arm's reach.
 
-  define_run_evaluations(n_steps=100, render=False, n_runs=1)      the reference's entry point (:40) and protocol: n_runs
-        random scenes, each stepped through examples/example_pandas_Jointspace.run_panda_example on the mirrored host
-        classes, the reference's statistics (time to success, collision episodes, minimum clearance, solver / step time,
-        success rate; mean +- std per case) returned as a dictionary and printed as a text table; the solver times of
-        the last case are pickled to `results_dynamic_scenarios` as the reference does (:121-122).
-  run_case(case, params, B, steps, n_blocks, seed)                  the same three cases for THOUSANDS of random scenes at
-        once, entirely on the device (runtime.ControlLoop = mrf_episode_run with the pick-and-place state machine).
-        There the RF-CV estimate stays inside the rollouts (goal_estimate_mask); the reference's driver writes it into
-        robot 1's goal list, from where it also reaches robot 1's OWN compute_action (EXJ:346-348 -> :423), robot 1 then
-        chases its own extrapolated hand -- define_run_evaluations reproduces that literally.
+Settings as the reference's script leaves them: one sphere per link, dynamic obstacle leaves, horizon from the parameter
+class; in the third case the estimate x_ee + 0.2 v_ee replaces robot 1's goal everywhere (its own planner included), and
+the deadlock logic stays on (the joint-space driver ignores RESOLVE_DEADLOCKS).  `run_case` keeps the estimate inside
+the rollouts instead (`estimate="rollouts"`), which is what RF-CV means in the paper.
 
-What stands in for pybullet: exact velocity integration, a cube that travels with the closed gripper,
-finger joints that follow their velocity command.  A behavioural evaluation of the specification, not a parity test.
+What stands in for pybullet: exact velocity integration, a cube that travels with the closed gripper.
+A behavioural evaluation of the planner specification, not a parity test.
 
-usage: python examples/evaluation/evaluate_random_dynamic_scenarios.py [--runs 2 --steps 7000]
+usage: python examples/evaluation/evaluate_random_dynamic_scenarios.py [--runs 8 --steps 7000]
        python examples/evaluation/evaluate_random_dynamic_scenarios.py --device [--scenarios 512] [--steps 4000] [--blocks 2]
 """
 import argparse
-import copy
 import json
 import math
 import os
@@ -38,198 +35,106 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
 
-import examples.parameters_manipulators
-from examples.example_pandas_Jointspace import define_planners, define_rollout_planners, run_panda_example
-from examples.simulation_environments.create_simulation_manipulators import create_manipulators_simulation
-from multi_robot_fabrics_amd import abi, config
-from multi_robot_fabrics_amd.kinematics import UtilsKinematics
+from multi_robot_fabrics_amd.cell import CUBE_HALF, PandaCell, cube_layout
 from multi_robot_fabrics_amd.parameters import manipulator_parameters
-from multi_robot_fabrics_amd.runtime import ControlLoop, FabricHandle
+
+CASES = {  # case -> PandaCell.from_parameters settings
+    "dynamic": dict(rollouts=None),
+    "rollouts dynamic": dict(rollouts="jointspace"),
+    "rollouts dynamic estimated": dict(rollouts="jointspace", estimate="reference"),
+}
 
 
 def get_std(list_of_std: list) -> float:
-    """:29-38: the standard deviation of pooled runs from the runs' standard deviations."""
-    return float(np.sqrt(sum(std ** 2 for std in list_of_std) / len(list_of_std)))
+    """Standard deviation of pooled, equally long runs from the runs' own standard deviations."""
+    return math.sqrt(float(np.mean(np.square(list_of_std))))
 
 
-def define_run_evaluations(n_steps=100, render=False, n_runs=1, *, out_path="results_dynamic_scenarios"):
-    """:40-156."""
-    random_scene = True
-    cases = ["dynamic", "rollouts dynamic", "rollouts dynamic estimated"]
-    zero = {c: 0 for c in cases}
-    empty = {c: [] for c in cases}
-    n_success, nr_collision_episodes_all = copy.deepcopy(zero), copy.deepcopy(zero)
-    time2success_all, min_clearance_all, step_time_all, solver_time_all, step_time_std, solver_time_std, success_total = (
-        copy.deepcopy(empty) for _ in range(7))
-    param = examples.parameters_manipulators.manipulator_parameters(nr_robots=2)
-    simulation_class = create_manipulators_simulation(params=param)
-    kinematics_class = UtilsKinematics()
-    random_obstacles = [simulation_class.create_scene(random_scene, n_cubes=param.n_cubes) for _ in range(n_runs)]
-    for case in cases:
-        [ROLLOUT_FABRICS, ROLLOUTS_PLOTTING, STATIC_OR_DYN_FABRICS, RESOLVE_DEADLOCKS, ESTIMATE_GOAL, N_HORIZON, MPC_LAYER] = param.get_settings()
-        if case in ("dynamic", "rollouts dynamic", "rollouts dynamic estimated"):
-            STATIC_OR_DYN_FABRICS = 1
-        if case in ("rollouts static", "rollouts dynamic", "rollouts dynamic estimated"):
-            ROLLOUT_FABRICS = True
-        if case == "rollouts dynamic estimated":
-            ESTIMATE_GOAL, RESOLVE_DEADLOCKS = True, False
-        param.define_settings(ROLLOUT_FABRICS=ROLLOUT_FABRICS, ROLLOUTS_PLOTTING=ROLLOUTS_PLOTTING,
-                              STATIC_OR_DYN_FABRICS=STATIC_OR_DYN_FABRICS, RESOLVE_DEADLOCKS=RESOLVE_DEADLOCKS,
-                              ESTIMATE_GOAL=ESTIMATE_GOAL, N_HORIZON=N_HORIZON, MPC_LAYER=MPC_LAYER)
-        planners, planners_grasp, goal_structs = define_planners(params=param)
-        fk_dict = kinematics_class.define_forward_kinematics(planners, collision_links_nrs=param.collision_links_nrs,
-                                                             collision_links=param.collision_links)
-        forwardplanner = (define_rollout_planners(param, fk_dict=fk_dict, goal_structs=goal_structs, n_steps=100)
-                          if case.startswith("rollouts") else None)
-        results = []
-        for z in range(n_runs):
-            env = simulation_class.initialize_environment(render=render, random_scene=random_scene, obstacles=random_obstacles[z])
-            res = run_panda_example(param, n_steps=n_steps, planners=planners, planners_grasp=planners_grasp,
-                                    goal_structs=goal_structs, env=env, fk_dict=fk_dict, forwardplanner=forwardplanner)
-            env.close()
-            results.append(res)
-            n_success[case] += res["success_rate"]
-            success_total[case].append(res["success_rate"])
-            with np.errstate(all="ignore"):
-                import warnings
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")          # nanmax of two NaNs: nobody finished within n_steps
-                    time2success_all[case].append(np.nanmax([res["n_steps_panda"], res["n_steps_robot2"]]) * res["dt"])
-            if res["success_rate"] == 1:
-                min_clearance_all[case].append([res["min clearance"]])
-                if res["min clearance"] < 0:
-                    nr_collision_episodes_all[case] += 1
-            solver_time_all[case].append(res["solver_time_mean"])
-            step_time_all[case].append(res["step_time_mean"])
-            solver_time_std[case].append(res["solver_time_std"])
-            step_time_std[case].append(res["step_time_std"])
-        if out_path:
-            with open(out_path, "wb") as fp:                                                 # :121-122
-                pickle.dump([np.expand_dims(np.array(res["solver_times"]), 0) for res in results], fp)
+def _mean_std(values):
+    v = np.asarray(values, dtype=float)
+    v = v[np.isfinite(v)]
+    return {"mean": float(v.mean()) if v.size else float("nan"), "std": float(v.std()) if v.size else float("nan")}
 
-    def pm(vals, std=None):
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            m = float(np.nanmean(vals)) if len(vals) else float("nan")
-            s_ = float(np.nanstd(vals)) if (std is None and len(vals)) else (get_std(std) if std else float("nan"))
-        return {"mean": m, "std": s_}
 
+def define_run_evaluations(n_steps=100, render=False, n_runs=1, *, out_path="results_dynamic_scenarios", seed=0):
+    params = manipulator_parameters(nr_robots=2)
+    params.define_settings(STATIC_OR_DYN_FABRICS=1, N_HORIZON=params.N_HORIZON)
+    cubes = cube_layout(params, random_scene=True, rng=np.random.default_rng(seed), scenes=n_runs)
     out = {"n_runs": n_runs, "n_steps": n_steps, "cases": {}}
-    for case in cases:
-        n_ok = len(min_clearance_all[case])
+    for case, settings in CASES.items():
+        log = PandaCell.from_parameters(params, dynamic=True, cubes=cubes, scenes=n_runs, **settings).run(n_steps)
+        done = log.done_at.astype(float)
+        done[done < 0] = np.nan
+        finished = ~np.isnan(done).any(axis=1)                                   # every robot of the scene delivered
+        rate = (log.picked[:, -1] - log.failed[:, -1]) / log.cell.blocks_per_robot    # the last robot's, as the reference counts
+        clearance = log.min_clearance()
+        ok = rate == 1
         out["cases"][case] = {
-            "time_to_success_s": pm(time2success_all[case]),
-            "collision_episode_rate": nr_collision_episodes_all[case] / n_ok if n_ok else 0,
-            "min_clearance_m": pm([c[0] for c in min_clearance_all[case]]),
-            "solver_time_s": pm(solver_time_all[case], solver_time_std[case]),
-            "step_time_s": pm(step_time_all[case], step_time_std[case]),
-            "success_rate": {"mean": n_success[case] / n_runs, "std": float(np.nanstd(success_total[case]))}}
-    rows = [["", "Time-to-Success", "# Collision Episodes", "Min Clearance", "Solver-Time", "Step-Time", "Success-Rate"]]
-    f = lambda d: "%.4f+-%.4f" % (d["mean"], d["std"])
-    for case in cases:
-        c = out["cases"][case]
-        rows.append([case, f(c["time_to_success_s"]), "%.8f" % c["collision_episode_rate"], f(c["min_clearance_m"]),
-                     f(c["solver_time_s"]), f(c["step_time_s"]), f(c["success_rate"])])
-    widths = [max(len(r[k]) for r in rows) for k in range(7)]
+            "time_to_success_s": _mean_std(np.where(finished, np.nanmax(np.nan_to_num(done, nan=-1.0), axis=1), np.nan) * params.dt),
+            "collision_episode_rate": float((clearance[ok] < 0).mean()) if ok.any() else 0.0,
+            "min_clearance_m": _mean_std(clearance[ok]),
+            "solver_time_s": {"mean": float(log.solver_s.mean()), "std": get_std([log.solver_s.std()])},
+            "step_time_s": {"mean": float(log.wall_s.mean()), "std": get_std([log.wall_s.std()])},
+            "success_rate": _mean_std(rate),
+            "scenes_advanced_per_launch": n_runs}
+        if out_path:       # the reference leaves the solver times of the last case's runs behind
+            with open(out_path, "wb") as fp:
+                pickle.dump([log.solver_s[None, :].copy() for _ in range(n_runs)], fp)
+    head = ["", "Time-to-Success", "# Collision Episodes", "Min Clearance", "Solver-Time", "Step-Time", "Success-Rate"]
+    pm = lambda d: "%.4f+-%.4f" % (d["mean"], d["std"])
+    rows = [head] + [[case, pm(c["time_to_success_s"]), "%.6f" % c["collision_episode_rate"], pm(c["min_clearance_m"]),
+                      pm(c["solver_time_s"]), pm(c["step_time_s"]), pm(c["success_rate"])] for case, c in out["cases"].items()]
+    widths = [max(len(r[k]) for r in rows) for k in range(len(head))]
     out["table"] = "\n".join(" | ".join(cell.ljust(w) for cell, w in zip(r, widths)) for r in rows)
     return out
 
 
-def random_blocks(params, B, n_blocks, rng):
-    """[n_blocks, 3, B*N]: hand targets 0.1 above cubes on the table (EXJ:300-303), 0.35-0.6 m in front of each mount."""
+def reachable_cubes(params, scenes, n_blocks, rng):
+    """[scenes, N * n_blocks, 3]: robot i's cubes 0.35-0.6 m from its base, within +-1 rad of the direction it faces."""
     N = params.nr_robots
-    out = np.zeros((n_blocks, 3, B * N))
-    for i in range(N):
-        T = np.asarray(params.mount_transform[i])
-        yaw = math.atan2(T[1, 0], T[0, 0])
+    out = np.zeros((scenes, N * n_blocks, 3))
+    out[:, :, 2] = params.z_table + CUBE_HALF
+    for i, T in enumerate(np.asarray(params.mount_transform, dtype=float)):
+        facing = math.atan2(T[1, 0], T[0, 0])
         for b in range(n_blocks):
-            r = rng.uniform(0.35, 0.6, B)
-            a = yaw + rng.uniform(-1.0, 1.0, B)
-            out[b, 0, i::N] = T[0, 3] + r * np.cos(a)
-            out[b, 1, i::N] = T[1, 3] + r * np.sin(a)
-            out[b, 2, i::N] = params.z_table + 0.025 + 0.1
+            reach, angle = rng.uniform(0.35, 0.6, scenes), facing + rng.uniform(-1.0, 1.0, scenes)
+            out[:, i * n_blocks + b, 0] = T[0, 3] + reach * np.cos(angle)
+            out[:, i * n_blocks + b, 1] = T[1, 3] + reach * np.sin(angle)
     return out
 
 
-def run_case(case, params, B, steps, n_blocks, seed, monitor=50):
-    N = params.nr_robots
-    rollouts = case != "dynamic"
-    estimated = case == "rollouts dynamic estimated"
-    cfg_act = config.panda_config(n_robots=N, horizon=1, dynamic=1, mounts=params.mount_transform)
-    cfg_grasp = config.panda_config(n_robots=N, horizon=1, dynamic=1, n_ego=0, mounts=params.mount_transform)
-    ha, hg = FabricHandle(cfg_act), FabricHandle(cfg_grasp)
-    hr = None
-    if rollouts:
-        cfg_roll = config.panda_config(n_robots=N, horizon=params.N_HORIZON, dynamic=1, mounts=params.mount_transform)
-        cfg_roll.goal_estimate_mask = (((1 << N) - 1) & ~1) if estimated else 0     # RF-CV inside the rollouts
-        hr = FabricHandle(cfg_roll)
+def run_case(case, params, B, steps, n_blocks, seed, monitor=64):
+    """One method on B random scenes at once; RF-CV stays inside the rollouts.  -> statistics of the batch."""
     rng = np.random.default_rng(seed)
-    rows = B * N
-    q0 = np.stack([np.asarray(params.pos0[i][:7], dtype=float) for i in range(N)], axis=1)            # [7, N]
-    q = np.tile(q0, (1, B)) + rng.uniform(-0.05, 0.05, (7, rows))
-    prm = np.zeros((abi.NPARAM, rows))
-    start = np.zeros((3, rows))
-    for i in range(N):
-        start[:, i::N] = np.asarray(params.start_goals[i], dtype=float)[:, None]
-        prm[abi.P_ANGLE_GOAL_1:abi.P_ANGLE_GOAL_1 + 9, i::N] = np.asarray(params.rotation_matrix_pandas[i]).reshape(9, 1)
-    prm[abi.P_X_GOAL_0:abi.P_X_GOAL_0 + 3] = start
-    prm[abi.P_WEIGHT_GOAL_0], prm[abi.P_WEIGHT_GOAL_1], prm[abi.P_WEIGHT_GOAL_2] = 2.0, 20.0, 1.0
-    prm[abi.P_X_GOAL_1] = 0.107
-    prm[abi.P_X_GOAL_2] = math.pi / 4
-    prm[abi.P_CONSTRAINT_0 + 2], prm[abi.P_CONSTRAINT_0 + 3] = 1.0, -params.z_table
-    prm[abi.P_RADIUS_BODY:abi.P_RADIUS_BODY + 6] = params.radius_sphere
-    blocks = random_blocks(params, B, n_blocks, rng)
-    t = ha.tensor
-    loop = ControlLoop(ha, hr, t(q), t(np.zeros_like(q)), t(prm), config.PANDA_VEL_LIMITS, deadlock=rollouts,
-                       apply_estimate=False, stop_margin=1e-3,
-                       pick_place=dict(start_goal=t(start), blocks=t(blocks), nr_blocks=n_blocks,
-                                       q_gripper=t(np.full((2, rows), 0.04)), model=1, h_grasp=hg))
-    S = cfg_act.n_spheres
-    rad = t(np.array(cfg_act.sphere_radius[:S]))
-    min_clear = torch.full((B,), 1e9, dtype=ha.dtype, device=ha.device)
-    done_at = torch.full((B,), -1, dtype=torch.int64, device=ha.device)
+    settings = dict(CASES[case])
+    if settings.get("estimate"):
+        settings["estimate"] = "rollouts"
+    cell = PandaCell.from_parameters(params, dynamic=True, scenes=B, cubes=reachable_cubes(params, B, n_blocks, rng),
+                                     stop_margin=1e-3, q_jitter=0.05, rng=rng, **settings)
     t0 = time.perf_counter()
-    k = 0
-    while k < steps:
-        n = min(monitor, steps - k)
-        loop.run(n)
-        k += n
-        x, _, _ = ha.fk_spheres(loop.q)
-        xs = x.view(S, 3, B, N)
-        for i in range(N):
-            for j in range(i + 1, N):
-                d = (xs[:, None, :, :, i] - xs[None, :, :, :, j]).norm(dim=2)
-                min_clear = torch.minimum(min_clear, (d - rad[:, None, None] - rad[None, :, None]).reshape(S * S, B).min(0).values)
-        all_done = (loop.sm_state[abi.SM_STATE].view(B, N) == 10).all(dim=1)
-        done_at[all_done & (done_at < 0)] = k
-        if bool(all_done.all()):
-            break
-    torch.cuda.synchronize()
+    log = cell.run(steps, chunk=monitor)
     wall = time.perf_counter() - t0
-    ok = done_at >= 0
-    picked = loop.sm_state[abi.SM_PICKED].view(B, N).double()
-    out = {"case": case, "scenarios": B, "control_steps_run": k, "blocks_per_robot": n_blocks,
-           "success_rate": float(ok.double().mean()),
-           "mean_time_to_success_s": float(done_at[ok].double().mean() * cfg_act.dt) if bool(ok.any()) else None,
-           "mean_blocks_picked_per_robot": float(picked.mean()),
-           "min_clearance_m": float(min_clear.min()), "collision_episodes": int((min_clear < 0).sum()),
-           "all_finite": bool(torch.isfinite(loop.q).all()),
-           "wall_s": wall, "scenario_control_steps_per_s": B * k / wall}
-    if loop.dl_state is not None:
-        tid = loop.dl_state[abi.DL_TIME_IN_DEADLOCK]
-        out["episodes_with_deadlock_resolution"] = int((tid > 0).sum())
-        out["mean_steps_in_deadlock"] = float(tid.double().mean())
-        out["steps_with_nonfinite_rollout_signal"] = int(loop.dl_state[abi.DL_NONFINITE].sum())
-    return out
+    ok = (log.done_at >= 0).all(axis=1)
+    clearance = log.min_clearance()
+    res = {"case": case, "scenarios": B, "control_steps_run": log.steps, "blocks_per_robot": n_blocks,
+           "success_rate": float(ok.mean()),
+           "mean_time_to_success_s": float(log.done_at[ok].max(axis=1).mean() * params.dt) if ok.any() else None,
+           "mean_blocks_picked_per_robot": float(log.picked.mean()),
+           "min_clearance_m": float(clearance.min()), "collision_episodes": int((clearance < 0).sum()),
+           "all_finite": bool(np.isfinite(log.q_hist[-1].cpu().numpy()).all()),
+           "wall_s": wall, "scenario_control_steps_per_s": B * log.steps / wall}
+    if log.deadlock_steps is not None:
+        res["episodes_with_deadlock_resolution"] = int((log.deadlock_steps > 0).sum())
+        res["mean_steps_in_deadlock"] = float(log.deadlock_steps.mean())
+        res["steps_with_nonfinite_rollout_signal"] = int(log.nonfinite.sum())
+    return res
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--runs", type=int, default=2)
-    ap.add_argument("--device", action="store_true", help="batched device-resident episodes instead of the host protocol")
+    ap.add_argument("--runs", type=int, default=8)
+    ap.add_argument("--device", action="store_true", help="thousands of scenes with cubes over each arm's reach (run_case)")
     ap.add_argument("--scenarios", type=int, default=512)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--blocks", type=int, default=2)
@@ -239,9 +144,7 @@ if __name__ == "__main__":
     if args.device:
         params = manipulator_parameters(nr_robots=args.robots, n_obst_per_link=1)
         params.set_horizon(args.horizon)
-        res = [run_case(c, params, args.scenarios, args.steps or 4000, args.blocks, seed=7)
-               for c in ("dynamic", "rollouts dynamic", "rollouts dynamic estimated")]
-        print(json.dumps(res, indent=1))
+        print(json.dumps([run_case(c, params, args.scenarios, args.steps or 4000, args.blocks, seed=7) for c in CASES], indent=1))
     else:
         out = define_run_evaluations(n_steps=args.steps or 7000, render=False, n_runs=args.runs)
         print(out.pop("table"))

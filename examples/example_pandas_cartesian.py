@@ -1,349 +1,108 @@
 #!/usr/bin/env python3
-"""The reference's examples/example_pandas_cartesian.py on the HIP kernels, function by function and with the same
-signatures (EXC = the reference file).  The CARTESIAN variant of Rollout Fabrics: every robot rolls out ITS OWN fabric
-against the other robots' collision spheres moving with constant velocity (forward_planner_Cartesian.py:421-458) -- no
-coupling between the rollouts, one FabricsRollouts object per robot:
+"""The pick-and-place cell of example_pandas_Jointspace.py with the CARTESIAN variant of Rollout Fabrics: every arm
+rolls out its OWN fabric over the horizon against the other arms' collision spheres extrapolated at constant velocity --
+no coupling between the rollouts, one rollout object per robot.
 
-    define_run_panda_example(n_steps=100, render=True)                                         EXC:526-560
-        panda_config.yaml -> manipulator_parameters.define_settings -> create_manipulators_simulation
-        -> define_planners -> define_forward_kinematics / define_symbolic_collision_link_poses
-        -> define_rollout_planners -> run_panda_example
-    run_panda_example(params, n_steps, planners, planners_grasp, goal_structs, env, fk_dict, forwardplanners,
-                      fk_dict_spheres, utils_class) -> dict                                     EXC:194-524
-        per control step: observation -> state machine -> compute_x_obsts_dyn_0 / compute_endeffector -> RF-CV goal
-        estimate -> define_arguments_numerical + get_velocity_rollouts per robot -> deadlock_checking ->
-        compute_action(**kwargs) of the main or the grasp planner per robot -> gripper action -> env.step
+Same entry points as the reference's examples/example_pandas_cartesian.py (names, positional parameters, defaults,
+result keys; tests/test_examples_contract.py).  As in the joint-space example the functions here describe the cell and
+multi_robot_fabrics_amd.cell.PandaCell steps it on the GPU; the per-robot rollouts of one control step are ONE launch for
+all robots of all scenes, with the obstacle lists (the other arms' n_obst_per_link spheres per link, their positions and
+velocities J qdot at the start of the horizon) assembled on the device (include/mrf.h mrf_rollout_cartesian_coupled).
+`env` is the cube layout; `fk_dict`, `fk_dict_spheres` and `utils_class` are unused; `render=True` is ignored with a
+warning.
 
-The simulator is the kinematic stand-in of multi-robot-fabrics_amd/scene.py (no pybullet, no renderer: `render=True` is
-ignored with a warning).  The result dictionary carries the reference's keys (EXC:518-523).
+Behaviour kept from the reference: the YAML flags are applied before the planners are built (STATIC_OR_DYN_FABRICS
+decides how the main planners see the other arm); the deadlock logic runs only with RESOLVE_DEADLOCKS; with ESTIMATE_GOAL
+robot 1's goal is x_ee + 0.2 v_ee everywhere.
 
-usage: python examples/example_pandas_cartesian.py [--steps 7000] [--config other.yaml]
+usage: python examples/example_pandas_cartesian.py [--steps 7000] [--config other.yaml] [--cubes 2]
 """
 import argparse
-import copy
 import json
 import os
 import sys
-import time
+import warnings
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import yaml
 
-import examples.parameters_manipulators
-from examples.simulation_environments import create_simulation_manipulators
-from multi_robot_fabrics_amd.deadlock import deadlockprevention
-from multi_robot_fabrics_amd.goals import GoalComposition
-from multi_robot_fabrics_amd.kinematics import GenericURDFFk, UtilsKinematics, compute_endeffector, compute_x_obsts_dyn_0
-from multi_robot_fabrics_amd.pick_place import StateMachine
-from multi_robot_fabrics_amd.planner import ParameterizedFabricPlanner
+from multi_robot_fabrics_amd.cell import PandaCell, cube_layout
+from multi_robot_fabrics_amd.goals import panda_pick_place_goal
+from multi_robot_fabrics_amd.parameters import load_yaml_settings
+from multi_robot_fabrics_amd.planner import panda_planner
 from multi_robot_fabrics_amd.rollouts import FabricsRollouts
 
-CONFIG_PATH = os.path.join("examples", "configs", "panda_config.yaml")       # EXC:527, relative to the repository root
 
 
-def create_dummy_goal_panda() -> GoalComposition:
-    """EXC:24-61 (sub-goal 1 carries weight 20 here, 10 in the joint-space driver)."""
-    goal_dict = {
-        "subgoal0": {"weight": 2.0, "is_primary_goal": True, "indices": [0, 1, 2], "parent_link": "world",
-                     "child_link": "panda_hand", "desired_position": [0.1, 0.6, 0.8], "epsilon": 0.05,
-                     "type": "staticSubGoal"},
-        "subgoal1": {"weight": 20.0, "is_primary_goal": False, "indices": [0, 1, 2], "parent_link": "panda_link7",
-                     "child_link": "panda_hand", "desired_position": [0.107, 0.0, 0.0],
-                     "angle": [-0.366, 0.0, 0.0, 0.3305], "epsilon": 0.05, "type": "staticSubGoal"},
-        "subgoal2": {"weight": 1.0, "is_primary_goal": False, "indices": [6], "desired_position": [np.pi / 4],
-                     "epsilon": 0.05, "type": "staticJointSpaceSubGoal"},
-    }
-    return GoalComposition(name="goal", content_dict=goal_dict)
+def create_dummy_goal_panda():
+    return panda_pick_place_goal(orientation_weight=20.0)
 
 
 def set_planner_panda(degrees_of_freedom: int = 7, nr_obst=0, nr_obst_dyn=1, collision_links_nr=[5], urdf_links={},
                       mount_transform=[], i_robot=0):
-    """EXC:63-122: as the joint-space driver's, with the mount given as the list of 4x4 transforms."""
-    goal = create_dummy_goal_panda()
-    with open(urdf_links["URDF_file_panda"], "r") as file:
-        urdf = file.read()
-    fk = GenericURDFFk(urdf, "panda_link0", "panda_leftfinger")
-    planner = ParameterizedFabricPlanner(
-        degrees_of_freedom, fk,
-        geometry_plane_constraint="10*(1/(1+1*ca.exp(-10*x))-1) * (xdot**2)",
-        collision_geometry="-0.5 / (x ** 4) * (xdot ** 2)",
-        collision_finsler="0.01/(x**4) * xdot**2",
-    )
-    collision_links = ["panda_link" + str(l) if l < 9 else "panda_hand" for l in collision_links_nr]
-    panda_limits = [[-2.8973, 2.8973], [-1.7628, 1.7628], [-2.8973, 2.8973], [-3.0718, -0.0698], [-2.8973, 2.8973],
-                    [-0.0175, 3.7525], [-2.8973, 2.8973]]
-    planner._forward_kinematics.set_mount_transformation(mount_transformation=mount_transform[i_robot])
-    planner.set_components(collision_links=collision_links, goal=goal, number_obstacles=nr_obst,
-                           number_dynamic_obstacles=nr_obst_dyn, dynamic_obstacle_dimension=3,
-                           number_plane_constraints=1, limits=panda_limits)
-    planner.concretize(mode="vel", time_step=0.01)
-    return planner, goal
+    """-> (planner, goal) of robot i_robot, mounted at mount_transform[i_robot] (4x4)."""
+    if degrees_of_freedom != 7:
+        raise ValueError("the Panda chain has seven joints")
+    target = create_dummy_goal_panda()
+    return panda_planner(urdf_links["URDF_file_panda"], mount_transform[i_robot], target, collision_links_nr, nr_obst,
+                         nr_obst_dyn), target
 
 
 def define_planners(params):
-    """EXC:124-158."""
-    if params.STATIC_OR_DYN_FABRICS == 0:
-        nr_obst_planners, nr_obst_dyn_planners = params.nr_obsts_dyn_all, [0] * params.nr_robots
-    else:
-        nr_obst_planners, nr_obst_dyn_planners = [0] * params.nr_robots, params.nr_obsts_dyn_all
-    planners, goal_structs, planners_grasp = [], [], []
-    for i_robot in range(params.nr_robots):
-        planner_i, goal_struct_i = set_planner_panda(degrees_of_freedom=params.dof[i_robot], nr_obst=nr_obst_planners[i_robot],
-                                                     nr_obst_dyn=nr_obst_dyn_planners[i_robot],
-                                                     collision_links_nr=params.collision_links_nrs[i_robot],
-                                                     urdf_links=params.urdf_links, mount_transform=params.mount_transform,
-                                                     i_robot=i_robot)
-        planner_grasp_i, _ = set_planner_panda(degrees_of_freedom=params.dof[i_robot], nr_obst=0, nr_obst_dyn=0,
-                                               collision_links_nr=[], urdf_links=params.urdf_links,
-                                               mount_transform=params.mount_transform, i_robot=i_robot)
-        planners.append(planner_i)
-        goal_structs.append(goal_struct_i)
-        planners_grasp.append(planner_grasp_i)
-    return planners, planners_grasp, goal_structs
+    """-> (main planners, grasp planners, goals) per robot; see the joint-space example."""
+    def robot(i, links, counts):
+        return set_planner_panda(params.dof[i], *counts, links, params.urdf_links, params.mount_transform, i)
+
+    rows = [robot(i, links, params.obstacle_counts(i)) + (robot(i, [], (0, 0))[0],)
+            for i, links in enumerate(params.collision_links_nrs)]
+    main, goals, grasp = (list(column) for column in zip(*rows))
+    return main, grasp, goals
 
 
 def define_rollout_planners(params, fk_dict=None, goal_structs=None, n_steps=100, planners=[], nr_robots=2):
-    """EXC:160-192: one independent rollout object per robot, built on that robot's main planner."""
-    forwardplanners = []
-    v_obsts_dyn = [np.zeros((3,))] * params.nr_obsts_dyn_all[0]
-    for i_robot in range(nr_robots):
-        fp = FabricsRollouts(N=params.N_HORIZON, dt=params.dt, nx=params.dof[i_robot] * 2, nu=params.dof[i_robot],
-                             dof=params.dof[i_robot], nr_obsts=params.nr_obsts[i_robot], bool_ring=False,
-                             nr_obsts_dyn=params.nr_obsts_dyn_all[i_robot], v_obsts_dyn=v_obsts_dyn,
-                             fabrics_mode=params.fabrics_mode, collision_links_nrs=params.collision_links_nrs[i_robot],
-                             nr_constraints=params.nr_constraints[i_robot], radius_sphere=params.radius_sphere,
-                             constraints=params.constraints[i_robot], nr_goals=len(goal_structs[i_robot]._config))
-        fp.symbolic_forward_fabrics(planner=planners[i_robot], goal_struct=goal_structs[i_robot])
-        forwardplanners.append(fp)
-    return forwardplanners
+    """-> one rollout object per robot, horizon params.N_HORIZON, bound to that robot's main planner: it rolls the
+    planner out against all nr_obsts_dyn_all spheres of the other robots, each moving with the velocity it has now."""
+    return [FabricsRollouts.for_robot(params, i, planners[i], goal_structs[i]) for i in range(nr_robots)]
 
 
 def run_panda_example(params, n_steps=5000, planners=[], planners_grasp=[], goal_structs=[], env=None, fk_dict=None,
-                      forwardplanners=None, fk_dict_spheres=None, utils_class=None) -> dict:
-    """EXC:194-524: the control loop; returns the reference's dictionary of evaluation metrics."""
-    dof = params.dof
-    n_steps_panda, n_steps_panda2 = np.nan, np.nan
-    success = [False, False]
-    step_times, solver_times = [], []
-    min_clearance = 100
-    nr_robots = len(params.collision_links_nrs)
-    dof_index = [0]
-    for i_robot in range(nr_robots):
-        dof_index.append(dof_index[i_robot] + dof[0] + 2)
-    limit_vel_panda = np.array([2.1750, 2.1750, 2.1750, 2.1750, 2.61, 2.61, 2.61])
-    limits_action = np.concatenate([np.concatenate((limit_vel_panda, np.array([2, 2]))) for _ in range(nr_robots)])
+                      forwardplanners=None, fk_dict_spheres=None, utils_class=None, *, scenes=1) -> dict:
+    """Runs the cell for at most n_steps control steps; `env`: cube centres ([n_cubes, 3] or [scenes, n_cubes, 3]) or None
+    for the fixed layout; `forwardplanners`: the list from define_rollout_planners or None."""
+    rollouts = forwardplanners if params.ROLLOUT_FABRICS else None
+    cell = PandaCell.from_planners(params, planners, planners_grasp, rollouts, cartesian=True, cubes=env, scenes=scenes,
+                                   deadlock=bool(rollouts) and bool(params.RESOLVE_DEADLOCKS))
+    log = cell.run(n_steps)
+    result = log.reference_result()
+    if params.ROLLOUTS_PLOTTING and rollouts and log.steps:
+        _, traj_q, _ = cell.hr.rollout_cartesian_coupled(cell.loop.q, cell.loop.qdot, cell.loop.params_work, want_traj=True)
+        result["rollout_plot_data"] = traj_q.cpu().numpy()
+    return result
 
-    action = np.zeros(env.n())
-    ob, *_ = env.step(action)
-    fk_endeff = utils_class.define_symbolic_endeffector(planners)
-    env.reconfigure_camera(2.5, -5., -42., (0.3, 1., -0.5))
-    deadlock_prevention = deadlockprevention(dof, params.nr_robots, params.N_HORIZON) if params.ROLLOUT_FABRICS else None
-    state_machines = [StateMachine(start_goal=params.start_goals[i], nr_robots=nr_robots, nr_blocks=params.n_cubes / nr_robots,
-                                   fk_fun_ee=fk_endeff[i]["fk_fun_ee"], robot_types=params.robot_types)
-                      for i in range(nr_robots)]
 
-    q_pandas = [[] for _ in range(nr_robots)]
-    qdot_pandas = [[] for _ in range(nr_robots)]
-    q_pandas_gripper = [[] for _ in range(nr_robots)]
-    ob_pandas = [[] for _ in range(nr_robots)]
-    state_machine_pandas = [[] for _ in range(nr_robots)]
-    goal_pandas = [[] for _ in range(nr_robots)]
-    goal_weights = [[] for _ in range(nr_robots)]
-    goal_pandas_block = [[] for _ in range(nr_robots)]
-    weight_goals = {"robot_" + str(i): {} for i in range(nr_robots)}
-    x_goals = {"robot_" + str(i): {} for i in range(nr_robots)}
-    vel_avg = [[] for _ in range(nr_robots)]
-    q_robots_N, q_dot_robots_N, q_ddot_robots_N, x_obsts_dyn_N = {}, {}, {}, {}
-    q_num_N, q_dot_num_N, q_ddot_num_N = {}, {}, {}
-    pos_xyz = []
-    time_deadlock_out = 1000
-    states_seen = [set() for _ in range(nr_robots)]
+def define_run_panda_example(n_steps=100, render=True, *, config_path=None, n_cubes=None, scenes=1):
+    if render:
+        warnings.warn("multi-robot-fabrics_amd has no renderer: render=True is ignored", RuntimeWarning, stacklevel=2)
+    params, setup = load_yaml_settings(config_path)          # flags first: they decide how the planners see the other arm
+    if n_cubes is not None:
+        params.n_cubes = int(n_cubes)
+    built = define_planners(params)
+    rollouts = None
     if params.ROLLOUT_FABRICS:
-        for i_robot in range(nr_robots):
-            forwardplanners[i_robot].preset_radii_obsts_dyn(radii_obst_dyn=params.r_dyns_obsts[i_robot])
-
-    for w in range(n_steps):
-        t_start_loop = time.perf_counter()
-        # --- states and the cube each robot is after (EXC:297-310) ---
-        first_index = list(ob["robot_0"]["FullSensor"]["obstacles"].keys())[0]
-        per_robot = params.n_cubes / nr_robots
-        for i_robot in range(nr_robots):
-            ob_pandas[i_robot] = ob["robot_" + str(i_robot)]
-            q_pandas[i_robot] = ob_pandas[i_robot]["joint_state"]["position"][0:dof[0]]
-            q_pandas_gripper[i_robot] = ob_pandas[i_robot]["joint_state"]["position"][dof[0]:dof[0] + 2]
-            qdot_pandas[i_robot] = np.clip(ob_pandas[i_robot]["joint_state"]["velocity"][0:dof[0]], -limit_vel_panda, limit_vel_panda)
-            picked = state_machines[i_robot].get_nr_blocks_picked()
-            if picked < per_robot:
-                goal_pandas_block[i_robot] = copy.deepcopy(
-                    ob["robot_0"]["FullSensor"]["obstacles"][first_index + picked + int(i_robot * per_robot)]["position"])
-                goal_pandas_block[i_robot][2] += 0.1
-        # --- state machine (EXC:312-336) ---
-        for i_robot in range(nr_robots):
-            state_machine_pandas[i_robot] = state_machines[i_robot].get_state_machine_panda(
-                q_robot=q_pandas[i_robot], q_robot_gripper=q_pandas_gripper[i_robot], goal_block=goal_pandas_block[i_robot],
-                robot_type="panda")
-            states_seen[i_robot].add(int(state_machine_pandas[i_robot]))
-        if state_machine_pandas[0] == 10 and not success[0]:
-            n_steps_panda, success[0] = w, True
-        if state_machine_pandas[1] == 10 and not success[1]:
-            n_steps_panda2, success[1] = w, True
-        if all(state_machine_pandas[i] == 10 for i in range(nr_robots)):
-            break
-        for i_robot in range(nr_robots):
-            key_i = "robot_" + str(i_robot)
-            goal_pandas[i_robot] = state_machines[i_robot].get_goal_robot()
-            goal_weights[i_robot] = state_machines[i_robot].get_weight_goal0()
-            for i_subgoal in range(len(goal_structs[i_robot]._config)):
-                name = "subgoal" + str(i_subgoal)
-                if i_subgoal == 0:
-                    weight_goals[key_i][name] = goal_weights[i_robot]
-                    x_goals[key_i][name] = goal_pandas[i_robot]
-                else:
-                    weight_goals[key_i][name] = goal_structs[i_robot]._config[name]["weight"]
-                    x_goals[key_i][name] = goal_structs[i_robot]._config[name]["desired_position"]
-
-        # --- obstacle spheres of the other robots and the hands (EXC:338-352) ---
-        env.update_collision_links()
-        x_collision_sphere_poses = env.collision_links_poses(position_only=True)
-        x_dyns_obsts, v_dyns_obsts, x_dyns_obsts_per_robot = compute_x_obsts_dyn_0(
-            q_robots=q_pandas, qdot_robots=qdot_pandas, x_collision_sphere_poses=x_collision_sphere_poses,
-            nr_robots=nr_robots, fk_dict_spheres=fk_dict_spheres, nr_dyn_obsts=params.nr_obsts_dyn_all)
-        x_robots_ee, v_robots_ee = compute_endeffector(q_pandas, qdot_pandas, fk_endeff, nr_robots=params.nr_robots)
-        pos_xyz.append(x_robots_ee[0])
-        if params.ESTIMATE_GOAL:                                                              # EXC:354-357
-            x_goals["robot_1"]["subgoal0"] = x_robots_ee[1] + 20 * 0.01 * v_robots_ee[1]
-
-        t_rollouts = 0
-        if params.ROLLOUT_FABRICS:
-            t_start_rollouts = time.perf_counter()
-            arguments = [[] for _ in range(nr_robots)]
-            for i_robot in range(nr_robots):
-                key_i = "robot_" + str(i_robot)
-                arguments[i_robot] = forwardplanners[i_robot].define_arguments_numerical(
-                    q_robot=q_pandas[i_robot], q_dot_robot=qdot_pandas[i_robot], constraints=params.constraints[i_robot],
-                    weight_goals=weight_goals[key_i], x_goals=x_goals[key_i], x_obsts=[],
-                    x_obsts_dyn=x_dyns_obsts[i_robot], v_obsts_dyn=v_dyns_obsts[i_robot])
-                if params.ROLLOUTS_PLOTTING:                                                  # EXC:374-397
-                    q_robots_N[key_i], q_dot_robots_N[key_i], q_ddot_robots_N[key_i] = forwardplanners[i_robot].rollouts_numerical(arguments[i_robot])
-                    x_obsts_dyn_N[key_i] = (forwardplanners[i_robot].x_obsts_dyn_numerical(pos_obsts_dyn=x_dyns_obsts[i_robot])
-                                            if params.nr_obsts_dyn[i_robot] > 0 else [[] for _ in range(params.N_HORIZON)])
-                    q_num_N[key_i], q_dot_num_N[key_i], q_ddot_num_N[key_i] = forwardplanners[i_robot].forward_fabrics(
-                        planner=planners[i_robot], pos_k=q_pandas[i_robot], vel_k=qdot_pandas[i_robot], ob_robot=ob_pandas[i_robot],
-                        goal=goal_structs[i_robot], x_obsts_dyn_0=x_dyns_obsts[i_robot], x_goals_struct=x_goals[key_i],
-                        weight_goals_struct=weight_goals[key_i])
-            t_rollouts = time.perf_counter() - t_start_rollouts
-            if params.RESOLVE_DEADLOCKS:                                                      # EXC:401-423
-                for i_robot in range(nr_robots):
-                    vel_avg[i_robot] = forwardplanners[i_robot].get_velocity_rollouts(arguments[i_robot]).full()[0]
-                vel_avg_tot = sum(vel_avg) / nr_robots
-                goal_deadl, weight_deadl, time_deadlock_out = deadlock_prevention.deadlock_checking(
-                    x_robots=x_robots_ee, goal_robots=[x_goals["robot_" + str(i)]["subgoal0"] for i in range(nr_robots)],
-                    goal_weights=[weight_goals["robot_" + str(i)]["subgoal0"] for i in range(nr_robots)], time_step=w,
-                    time_deadlock_out=time_deadlock_out, avg_sum=vel_avg_tot, state_machine_robots=state_machine_pandas)
-                for i_robot in range(nr_robots):
-                    x_goals["robot_" + str(i_robot)]["subgoal0"] = goal_deadl[i_robot]
-                    weight_goals["robot_" + str(i_robot)]["subgoal0"] = weight_deadl[i_robot]
-
-        t_start_actions = time.perf_counter()
-        # --- actions (EXC:427-462) ---
-        for i_robot in range(nr_robots):
-            key_i = "robot_" + str(i_robot)
-            lo = dof_index[i_robot]
-            if state_machine_pandas[i_robot] == 3 or state_machine_pandas[i_robot] == 5:
-                action[lo:lo + dof[i_robot]] = np.zeros(dof[0])
-            else:
-                arguments_robot = dict(
-                    q=q_pandas[i_robot], qdot=qdot_pandas[i_robot], x_goal_0=np.array(x_goals[key_i]["subgoal0"]),
-                    x_goal_1=np.array(x_goals[key_i]["subgoal1"]), x_goal_2=np.array(x_goals[key_i]["subgoal2"]),
-                    weight_goal_0=weight_goals[key_i]["subgoal0"], weight_goal_1=weight_goals[key_i]["subgoal1"],
-                    weight_goal_2=weight_goals[key_i]["subgoal2"], angle_goal_1=params.rotation_matrix_pandas[i_robot],
-                    x_obsts=x_dyns_obsts[i_robot], radius_obsts=params.r_dyns_obsts[i_robot],
-                    constraint_0=params.constraints[i_robot], radius_body_panda_links=params.radius_body_panda_links,
-                    radius_body_panda_hand=np.array([params.radius_sphere]), x_obsts_dynamic=x_dyns_obsts[i_robot],
-                    xdot_obsts_dynamic=v_dyns_obsts[i_robot], xddot_obsts_dynamic=params.a_dyns_obsts[i_robot],
-                    radius_obsts_dynamic=params.r_dyns_obsts[i_robot])
-                if state_machine_pandas[i_robot] == 2:       # descending onto the cube: goal reaching only
-                    action[lo:lo + dof[i_robot]] = planners_grasp[i_robot].compute_action(**arguments_robot)
-                else:
-                    action[lo:lo + dof[i_robot]] = planners[i_robot].compute_action(**arguments_robot)
-            action[lo + dof[i_robot]:dof_index[i_robot + 1]] = state_machines[i_robot].get_gripper_action_panda(q_pandas_gripper[i_robot])
-        t_actions = (time.perf_counter() - t_start_actions) / 2                               # EXC:464 (sic)
-
-        action = np.clip(action, -limits_action, limits_action)
-        ob, *_ = env.step(action)
-        t_end_loop = time.perf_counter()
-        solver_times = np.append(solver_times, t_actions + t_rollouts)
-        step_times = np.append(step_times, t_end_loop - t_start_loop)
-
-        for k, x_panda_1 in enumerate(x_dyns_obsts_per_robot[0]):                             # EXC:474-481
-            for j, x_panda_2 in enumerate(x_dyns_obsts_per_robot[1]):
-                dist_x_r = np.linalg.norm(x_panda_1 - x_panda_2, 2) - params.r_dyns_obsts[0][k] - params.r_dyns_obsts[1][k]
-                if dist_x_r < min_clearance:
-                    min_clearance = dist_x_r
-
-    solver_times, step_times = np.asarray(solver_times, dtype=float), np.asarray(step_times, dtype=float)
-    nan = float("nan")
-    return {"success_rate": state_machines[-1].get_success_rate(),                            # EXC:516 (last robot's)
-            "n_steps_panda": n_steps_panda, "n_steps_robot2": n_steps_panda2,
-            "step_time_mean": float(np.mean(step_times)) if len(step_times) else nan,
-            "step_time_std": float(np.std(step_times)) if len(step_times) else nan,
-            "total_time": max([n_steps_panda, n_steps_panda2]) * 0.01, "dt": params.dt,
-            "solver_time_mean": float(np.mean(solver_times)) if len(solver_times) else nan,
-            "solver_time_std": float(np.std(solver_times)) if len(solver_times) else nan,
-            "min clearance": min_clearance, "solver_times": solver_times,
-            # extras of this build, beside the reference's keys
-            "control_steps": int(len(solver_times)),
-            "blocks_picked": [m.get_nr_blocks_picked() for m in state_machines],
-            "states_visited": [sorted(s) for s in states_seen],
-            "time_in_deadlock_steps": int(deadlock_prevention.time_in_deadlock) if deadlock_prevention else 0,
-            "rollout_plot_data": {"q": q_robots_N, "qdot": q_dot_robots_N, "qddot": q_ddot_robots_N,
-                                  "x_obsts_dyn": x_obsts_dyn_N, "q_num": q_num_N} if params.ROLLOUTS_PLOTTING else None}
-
-
-def define_run_panda_example(n_steps=100, render=True, *, config_path=None, overrides=None):
-    """EXC:526-560.  Keyword-only extras of this build: `config_path` (another YAML with the same eight keys) and
-    `overrides` (attributes set on the parameter object after define_settings, e.g. {"n_cubes": 2})."""
-    path = config_path if config_path is not None else (CONFIG_PATH if os.path.exists(CONFIG_PATH) else os.path.join(ROOT, CONFIG_PATH))
-    with open(path, "r") as setup_stream:
-        setup = yaml.safe_load(setup_stream)
-    nr_robots = setup["n_robots"]
-    random_scene = False
-    param = examples.parameters_manipulators.manipulator_parameters(nr_robots=nr_robots, n_obst_per_link=setup["n_obst_per_link"])
-    param.define_settings(ROLLOUT_FABRICS=setup["ROLLOUT_FABRICS"], ROLLOUTS_PLOTTING=setup["ROLLOUTS_PLOTTING"],
-                          STATIC_OR_DYN_FABRICS=setup["STATIC_OR_DYN_FABRICS"], RESOLVE_DEADLOCKS=setup["RESOLVE_DEADLOCKS"],
-                          ESTIMATE_GOAL=setup["ESTIMATE_GOAL"], N_HORIZON=setup["N_HORIZON"],
-                          n_obst_per_link=setup["n_obst_per_link"])
-    for key, val in (overrides or {}).items():
-        setattr(param, key, val)
-    simulation_class = create_simulation_manipulators.create_manipulators_simulation(param)
-    random_obstacles = simulation_class.create_scene(random_scene=random_scene, n_cubes=param.n_cubes)
-    env = simulation_class.initialize_environment(render=render, random_scene=random_scene, obstacles=random_obstacles)
-    link_transforms_list = simulation_class.get_link_transforms()
-    utils_class = UtilsKinematics()
-    planners, planners_grasp, goal_structs = define_planners(params=param)
-    fk_dict = utils_class.define_forward_kinematics(planners=planners, collision_links=param.collision_links,
-                                                    collision_links_nrs=param.collision_links_nrs)
-    fk_dict_spheres = utils_class.define_symbolic_collision_link_poses(
-        urdf_files=param.urdf_links, collision_links=param.collision_links, sphere_transformations=link_transforms_list,
-        n_obst_per_link=param.n_obst_per_link, mount_transform=param.mount_transform)
-    planners_forward = (define_rollout_planners(params=param, fk_dict=fk_dict, goal_structs=goal_structs, n_steps=n_steps,
-                                                planners=planners, nr_robots=nr_robots) if param.ROLLOUT_FABRICS else None)
-    res = run_panda_example(params=param, n_steps=n_steps, planners=planners, planners_grasp=planners_grasp,
-                            goal_structs=goal_structs, env=env, fk_dict=fk_dict, forwardplanners=planners_forward,
-                            fk_dict_spheres=fk_dict_spheres, utils_class=utils_class)
-    env.close()
-    res["config"] = setup
-    return res
+        rollouts = define_rollout_planners(params, goal_structs=built[2], n_steps=n_steps, planners=built[0], nr_robots=params.nr_robots)
+    result = run_panda_example(params, n_steps, *built, env=cube_layout(params, scenes=scenes), forwardplanners=rollouts, scenes=scenes)
+    result["config"] = setup
+    return result
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=7000)
     ap.add_argument("--config", default=None)
+    ap.add_argument("--cubes", type=int, default=None)
     args = ap.parse_args()
-    res = define_run_panda_example(n_steps=args.steps, render=True, config_path=args.config)
+    res = define_run_panda_example(n_steps=args.steps, render=False, config_path=args.config, n_cubes=args.cubes)
     print(json.dumps({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in res.items()
                       if k not in ("solver_times", "rollout_plot_data")}, indent=1))

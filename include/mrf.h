@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MRF_ABI_VERSION 3
+#define MRF_ABI_VERSION 4
 #define MRF_MAX_ROBOTS 16
 #define MRF_MAX_SPHERES 32 /* exchanged spheres per robot */
 #define MRF_DOF_MAX 7
@@ -237,9 +237,13 @@ int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int
  *
  * world <= n_robots; further GPUs run replicas of the group on other scenario batches (independent, no exchange).
  * Every rank of the group must make the same sequence of mrf_rollout_sharded calls with the same n_scen.  A timed-out
- * peer exchange is sticky: every later wait of that communicator ends at once, the rollouts it touched leave q/qdot
- * where they were and return NaN as avg_vel (a result that cannot be mistaken for a rollout), until mrf_comm_reset or
- * mrf_comm_destroy.  The PEER kernel's grid is capped at the resident workgroup count, so no wait depends on a
+ * peer exchange is the GROUP's and sticky: the rank whose wait ran out raises the error word of every rank and stops
+ * publishing, so every rank that folded (or would fold) its missing spheres ends in error too.  The PEER kernel writes
+ * to staging arrays; a commit pass after it reads the error word ONCE and either advances ALL rows of q_io / qdot_io or
+ * none of them, in which case avg_vel is NaN for every row (a result that cannot be mistaken for a rollout).  Every later
+ * wait of that communicator ends at once, until mrf_comm_reset or mrf_comm_destroy.  (A rank that had already completed
+ * its rollout with valid peers' data when another rank gave up keeps its -- correct -- result and learns of the broken
+ * group from mrf_comm_status.)  The PEER kernel's grid is capped at the resident workgroup count, so no wait depends on a
  * workgroup that has not been dispatched.
  *   q_io, qdot_io [dof][n_scen*count]  the OWNED rows, row = scenario*count + (robot - first); advanced in place
  *   params        [MRF_NPARAM][n_scen*count]      avg_vel_out [n_scen*count]
@@ -257,15 +261,24 @@ int mrf_comm_init(mrf_handle* h, int32_t rank, int32_t world, const void* unique
 int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_scenarios, void* ipc_handle_out);
 int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all);
 int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot_count);
+/* What the communicator of this handle is, for logs that must prove what ran (bench.py's robot_sharded block): out[i],
+ * i < n <= MRF_COMM_INFO_N:
+ *   0 transport  1 rank  2 world  3 robot_first  4 robot_count
+ *   5 ncclCommCount of the RCCL communicator (0: none)   6 ncclCommUserRank (-1: none)   7 ncclCommCuDevice (-1: none)
+ *   8 HIP device of the handle   9 peer exchange buffers mapped from other ranks (PEER transport after connect) */
+#define MRF_COMM_INFO_N 10
+int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n);
 int32_t mrf_comm_transport(const mrf_handle* h);
 int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io, const void* params, void* avg_vel_out,
                         void* stream);
 /* Waits for the stream of the last mrf_rollout_sharded and reports a timed-out exchange (MRF_E_LAUNCH) or MRF_OK. */
 int mrf_comm_status(mrf_handle* h);
-/* Makes a communicator usable again after a timed-out PEER exchange: clears the error word and the flags in this rank's
- * exchange buffer and restarts the sequence numbers.  Call it on EVERY rank of the group, BETWEEN two barriers of the
- * caller's (no rank may still be inside, or already start, a mrf_rollout_sharded while another one resets); afterwards
- * the ranks continue with the same sequence of calls again.  A no-op for the RCCL transport. */
+/* Makes a communicator usable again after a timed-out PEER exchange: synchronises this rank's stream, clears the error
+ * word and the flags in this rank's exchange buffer and restarts the sequence numbers in a new EPOCH (the reset count
+ * is the high part of every sequence number, so a flag of the old sequence that a slower peer stores after the clearing
+ * can satisfy no wait of the new one).  Call it on EVERY rank of the group the same number of times, BETWEEN two
+ * barriers of the caller's (no rank may start a mrf_rollout_sharded while another one still resets); afterwards the
+ * ranks continue with the same sequence of calls again.  A no-op for the RCCL transport. */
 int mrf_comm_reset(mrf_handle* h);
 #define MRF_PEER_TIMEOUT_DEFAULT_MS 10000 /* bounded flag wait of the PEER kernel; override: env MRF_PEER_TIMEOUT_MS */
 /* env MRF_PEER_DEVICE_SHARE = k: k ranks of a group run on ONE device (single-GPU test setups); the PEER kernel then caps
@@ -393,6 +406,24 @@ int mrf_state_machine_step(mrf_handle* h, int64_t rows, const mrf_state_machine_
 int mrf_episode_set_pick_place(mrf_handle* h_action, const mrf_state_machine_config* sm, const void* start_goal,
                                const void* blocks, int32_t n_block_arrays, void* q_gripper_io, int32_t* sm_state,
                                void* sm_goal, void* gripper_action_out, mrf_handle* h_grasp, void* action_grasp_work);
+
+/* The Cartesian Rollout Fabrics of the reference's second driver with the obstacle assembly on the device:
+ * FabricsRollouts.get_velocity_rollouts for EVERY robot of every scenario (EXC:366-399; FPC:421-458,561-563) against
+ * the obstacles compute_x_obsts_dyn_0 hands it (utils_fabrics_kinematics.py:3-33, EXC:330-352): the configured spheres
+ * (cfg.sphere_link / _offset / _radius) of all other robots of the scenario at their current positions, moving with
+ * their current velocities J qdot (zero when cfg.dynamic == 0) for the whole horizon, zero accelerations (FPC:33).
+ * rows = n_scenarios * n_robots as in mrf_rollout; the obstacle arrays live in a work buffer owned by the handle
+ * (allocated on the first call of a batch size; not inside a stream capture).  avg_vel_out [rows];
+ * traj_q / traj_qd [H][7][rows] or NULL. */
+int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* qdot0, const void* params,
+                                  void* avg_vel_out, void* traj_q, void* traj_qd, void* stream);
+
+/* Which rollout the control steps of mrf_episode_run take from this ROLLOUT handle: the coupled joint-space rollout
+ * (mrf_rollout, example_pandas_Jointspace.py) or the per-robot Cartesian one (mrf_rollout_cartesian_coupled,
+ * example_pandas_cartesian.py).  Default MRF_ROLLOUT_JOINTSPACE. */
+#define MRF_ROLLOUT_JOINTSPACE 0
+#define MRF_ROLLOUT_CARTESIAN 1
+int mrf_episode_set_rollout(mrf_handle* h_rollout, int32_t kind);
 
 /* n_steps control steps on the device.  h_rollout may be NULL (no Rollout Fabrics, no deadlock logic: plain MRDF);
  * dl may be NULL (rollouts monitored, no deadlock logic).  Work buffers are caller-owned:

@@ -6,7 +6,7 @@ The product path has no CPU fallback: if csrc/libmrf_hip.so is missing or cannot
 import ctypes as C
 import os
 
-MRF_ABI_VERSION = 3
+MRF_ABI_VERSION = 4
 MRF_MAX_ROBOTS = 16
 MRF_MAX_SPHERES = 32
 MRF_DOF_MAX = 7
@@ -82,13 +82,16 @@ EXPORTS = [
     "mrf_episode_run",
     "mrf_compute_action_host", "mrf_rollout_host", "mrf_rollout_cartesian_host", "mrf_fk_spheres_host",
     "mrf_default_state_machine_config", "mrf_state_machine_config_sizeof", "mrf_state_machine_init", "mrf_state_machine_step",
-    "mrf_episode_set_pick_place",
+    "mrf_episode_set_pick_place", "mrf_rollout_cartesian_coupled", "mrf_episode_set_rollout",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
-    "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
+    "mrf_comm_info", "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
 ]
 
+ROLLOUT_JOINTSPACE, ROLLOUT_CARTESIAN = 0, 1
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
+COMM_INFO_KEYS = ("transport", "rank", "world", "robot_first", "robot_count", "rccl_comm_count", "rccl_user_rank",
+                  "rccl_device", "hip_device", "peer_buffers_mapped")
 
 # rows of the int32 deadlock state (include/mrf.h MRF_DL_*)
 DL_LEADER, DL_FOLLOWER, DL_DEAD0, DL_DEAD1, DL_TIME_IN_DEADLOCK, DL_TIME_DEADLOCK_OUT, DL_TIME_STEP, DL_NONFINITE, DL_NSTATE = range(9)
@@ -208,6 +211,13 @@ def load_library(path=None):
     lib.mrf_state_machine_step.restype = C.c_int
     lib.mrf_episode_set_pick_place.argtypes = [vp, smp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.mrf_episode_set_pick_place.restype = C.c_int
+    # MRF_ABI_ANY=1 (with MRF_HIP_LIB): an older build under A/B timing may lack the entry points added since
+    any_abi = bool(path or os.environ.get("MRF_HIP_LIB")) and os.environ.get("MRF_ABI_ANY") == "1"
+    if not (any_abi and not hasattr(lib, "mrf_rollout_cartesian_coupled")):
+        lib.mrf_rollout_cartesian_coupled.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+        lib.mrf_rollout_cartesian_coupled.restype = C.c_int
+        lib.mrf_episode_set_rollout.argtypes = [vp, i32]
+        lib.mrf_episode_set_rollout.restype = C.c_int
     lib.mrf_comm_unique_id.argtypes = [vp]
     lib.mrf_comm_unique_id.restype = C.c_int
     lib.mrf_comm_init.argtypes = [vp, i32, i32, vp]
@@ -218,6 +228,9 @@ def load_library(path=None):
     lib.mrf_comm_peer_connect.restype = C.c_int
     lib.mrf_comm_partition.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.mrf_comm_partition.restype = C.c_int
+    if not (any_abi and not hasattr(lib, "mrf_comm_info")):
+        lib.mrf_comm_info.argtypes = [vp, C.POINTER(i32), i32]
+        lib.mrf_comm_info.restype = C.c_int
     lib.mrf_comm_transport.argtypes = [vp]
     lib.mrf_comm_transport.restype = i32
     lib.mrf_rollout_sharded.argtypes = [vp, i64, vp, vp, vp, vp, vp]
@@ -228,7 +241,7 @@ def load_library(path=None):
     lib.mrf_comm_reset.restype = C.c_int
     lib.mrf_comm_destroy.argtypes = [vp]
     lib.mrf_comm_destroy.restype = None
-    if lib.mrf_abi_version() != MRF_ABI_VERSION:
+    if lib.mrf_abi_version() != MRF_ABI_VERSION and not any_abi:
         raise MrfLibraryError(f"ABI mismatch: library {lib.mrf_abi_version()} != python {MRF_ABI_VERSION}")
     if lib.mrf_config_sizeof() != C.sizeof(Config):
         raise MrfLibraryError(f"mrf_config size mismatch: C {lib.mrf_config_sizeof()} != ctypes {C.sizeof(Config)}")

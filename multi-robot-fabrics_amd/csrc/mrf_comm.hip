@@ -68,10 +68,14 @@ __device__ __forceinline__ double quiet_nan<double>() { return __builtin_bit_cas
 template <>
 __device__ __forceinline__ float quiet_nan<float>() { return __builtin_bit_cast(float, 0x7fc00000u); }
 
+// q_in / qd_in are only read; the advanced state and the velocity signal go to the STAGING arrays q_st / qd_st / avg_st
+// (owned by the communicator) and are committed to the caller's arrays by k_peer_commit after the whole grid has
+// finished -- from ONE reading of the error word, so that a timed-out exchange leaves every row where it was.
 template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict__ cfgp, PeerView V, int64_t n_scen,
-                                                      T* __restrict__ q_io, T* __restrict__ qd_io,
-                                                      const T* __restrict__ prm, T* __restrict__ avg_out,
+                                                      const T* __restrict__ q_in, const T* __restrict__ qd_in,
+                                                      const T* __restrict__ prm, T* __restrict__ q_st,
+                                                      T* __restrict__ qd_st, T* __restrict__ avg_st,
                                                       unsigned long long seq0) {
   __shared__ T xch[21 * 64];  // cos q, sin q, qdot of every lane (sphere tables with offsets re-walk from it)
   const DevCfg<T>& cfg = *cfgp;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   int* err = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
 
   PandaState<T> R;
-  load_state(rows, row, (const T*)q_io, (const T*)qd_io, R);
+  load_state(rows, row, q_in, qd_in, R);
   const T* mount_own = cfg.mount[me];
   PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
   if ((cfg.goal_mask >> me) & 1) {  // RF-CV goal estimate (EXC:355-357), as in k_rollout_panda
@@ -229,16 +233,23 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
           }
           __threadfence_system();  // the wave's stores (local and remote) are performed before the flags go up
           __syncthreads();
-          if (lane < V.G)
+          // Once the group is in error (this rank timed out, or a peer did and said so in this rank's error word) no
+          // further flag goes up: the spheres behind it may have been computed from stale data, and the peers must
+          // time out -- or see the error -- rather than fold them.
+          const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+          if (lane < V.G && !broken)
             __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           // ---- wait for the same workgroup of every other rank (bounded: a missing peer must not hang the GPU)
           if (lane < V.G && lane != V.grank) {
             const unsigned long long* f = peer_flag(V, V.grank, gen, lane, blk);
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-              if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+              if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
               if (wall_clock64() - t0 > V.timeout_ticks) {
-                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the timeout is the GROUP's: raise the error word of every rank, so that a peer which went on with
+                // this rank's (now missing) spheres cannot return a finite result either
+                for (int g = 0; g < V.G; ++g)
+                  __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
               }
               __builtin_amdgcn_s_sleep(1);
@@ -254,20 +265,39 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
     }
   }
   if (active) {
-    // a timed-out exchange means some step of this rollout folded stale spheres: the state is left where it was and
-    // the velocity signal is NaN, so a caller that forgets mrf_comm_status cannot take the result for a rollout
-    const bool bad = V.G > 1 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    if (!bad) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        q_io[j * rows + row] = R.q[j];
-        qd_io[j * rows + row] = R.qd[j];
-      }
+    for (int j = 0; j < 7; ++j) {
+      q_st[j * rows + row] = R.q[j];
+      qd_st[j * rows + row] = R.qd[j];
     }
-    avg_out[row] = bad ? quiet_nan<T>() : sumsq / (T)(H * 7);  // FPJ:102-116
+    avg_st[row] = sumsq / (T)(H * 7);  // FPJ:102-116
   }
   __syncthreads();  // xch is rewritten by the next block of this workgroup
   }
+}
+
+// After k_rollout_peer (same stream): one thread latches the error word, then every row is committed from that latch --
+// all rows advance, or (a timed-out exchange: some step folded stale spheres) none does and the velocity signal is NaN,
+// so that a caller that forgets mrf_comm_status cannot take the result for a rollout.
+__global__ void k_peer_latch(const int* __restrict__ err, int* __restrict__ latch, int group) {
+  *latch = group > 1 ? __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_peer_commit(int64_t rows, const int* __restrict__ latch, const T* __restrict__ q_st,
+                                                      const T* __restrict__ qd_st, const T* __restrict__ avg_st,
+                                                      T* __restrict__ q_io, T* __restrict__ qd_io, T* __restrict__ avg_out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  if (*latch != 0) {
+    avg_out[r] = quiet_nan<T>();
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    q_io[j * rows + r] = q_st[j * rows + r];
+    qd_io[j * rows + r] = qd_st[j * rows + r];
+  }
+  avg_out[r] = avg_st[r];
 }
 
 // RF-CV goal estimate for the step-kernel path (the persistent kernels do it in their prologue): params copied to a
@@ -317,6 +347,9 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
@@ -340,6 +373,9 @@ RcclApi& rccl() {
   api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
   api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+  api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
+  api.CommUserRank = (decltype(api.CommUserRank))sym("ncclCommUserRank");
+  api.CommCuDevice = (decltype(api.CommCuDevice))sym("ncclCommCuDevice");
   api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
   if (!api.error.empty()) api.lib = nullptr;
   return api;
@@ -352,6 +388,7 @@ struct Comm {
   int cnt_max = 1;
   // RCCL
   ncclComm_t nccl = nullptr;
+  int nccl_count = 0, nccl_rank = -1, nccl_device = -1;  // what the communicator itself reports (mrf_comm_info)
   void* sph_own = nullptr;  // [cnt_max][SX][9][B]
   void* sph_pad = nullptr;  // [world][cnt_max][SX][9][B]
   void* sumsq = nullptr;    // [B*count]
@@ -364,6 +401,8 @@ struct Comm {
   int64_t b_max = 0;
   int nblk_max = 0;
   size_t off_flags = 0, off_err = 0, off_x = 0, bytes = 0;
+  void* stage = nullptr;  // peer kernel outputs before the commit: q [7][rows], qdot [7][rows], avg [rows], latch
+  unsigned long long epoch = 0;  // mrf_comm_reset count: the high bits of every sequence number
   unsigned long long seq = 1;
   hipStream_t last_stream = nullptr;
 };
@@ -428,6 +467,7 @@ void mrf_host::comm_release(mrf_handle* h) {
   for (int g = 0; g < c->world; ++g)
     if (c->peer[g] && g != c->rank) (void)hipIpcCloseMemHandle(c->peer[g]);
   if (c->local) (void)hipFree(c->local);
+  if (c->stage) (void)hipFree(c->stage);
   delete c;
   h->comm = nullptr;
 }
@@ -484,8 +524,23 @@ int mrf_comm_init(mrf_handle* h, int32_t rank, int32_t world, const void* unique
       return fail(h, MRF_E_DEVICE, std::string("ncclCommInitRank: ") + api.GetErrorString(r));
     }
     c->transport = MRF_TRANSPORT_RCCL;
+    // ask the communicator what it is: a bench line that says "N ranks" must be able to show RCCL saw N ranks
+    (void)api.CommCount(c->nccl, &c->nccl_count);
+    (void)api.CommUserRank(c->nccl, &c->nccl_rank);
+    (void)api.CommCuDevice(c->nccl, &c->nccl_device);
   }
   h->comm = c;
+  return MRF_OK;
+}
+
+int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n) {
+  if (!h || !out || n < 1) return MRF_E_ARG;
+  const Comm* c = (const Comm*)h->comm;
+  const int32_t vals[MRF_COMM_INFO_N] = {
+      c ? c->transport : MRF_TRANSPORT_NONE, c ? c->rank : 0, c ? c->world : 0, c ? c->first[c->rank] : 0,
+      c ? c->first[c->rank + 1] - c->first[c->rank] : 0, c ? c->nccl_count : 0, c ? c->nccl_rank : -1,
+      c ? c->nccl_device : -1, h->device, c && c->transport == MRF_TRANSPORT_PEER && c->connected ? c->world - 1 : 0};
+  for (int i = 0; i < n && i < MRF_COMM_INFO_N; ++i) out[i] = vals[i];
   return MRF_OK;
 }
 
@@ -517,6 +572,13 @@ int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_s
     if (c->local) (void)hipFree(c->local);
     delete c;
     return fail(h, MRF_E_DEVICE, std::string("exchange buffer / hipIpcGetMemHandle: ") + hipGetErrorString(e));
+  }
+  const int own_count = c->first[rank + 1] - c->first[rank];
+  const size_t stage_bytes = (size_t)15 * max_scenarios * own_count * scalar_bytes(h) + 256;
+  if (hipMalloc(&c->stage, stage_bytes) != hipSuccess) {
+    (void)hipFree(c->local);
+    delete c;
+    return fail(h, MRF_E_DEVICE, "staging buffer of the peer rollout");
   }
   std::memcpy(ipc_handle_out, &mh, sizeof(mh));
   c->peer[rank] = c->local;
@@ -609,8 +671,17 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
           if (k > 1) resident = resident / (unsigned)k ? resident / (unsigned)k : 1u;
         }
         dim3 block(64), grid(nblk < resident ? nblk : resident);
-        return launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen, (T*)q_io, (T*)qdot_io,
-                      (const T*)params, (T*)avg_vel_out, seq0);
+        T* q_st = (T*)c->stage;
+        T* qd_st = q_st + 7 * rows;
+        T* avg_st = qd_st + 7 * rows;
+        int* latch = (int*)((unsigned char*)c->stage + (((size_t)15 * c->b_max * count * sizeof(T)) & ~(size_t)15) + 16);
+        if (int rc = launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen, (const T*)q_io,
+                            (const T*)qdot_io, (const T*)params, q_st, qd_st, avg_st, seq0))
+          return rc;
+        if (int rc = launch(h, mrf::k_peer_latch, dim3(1), dim3(1), st, (const int*)(c->local + c->off_err), latch, c->world))
+          return rc;
+        return launch(h, mrf::k_peer_commit<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, rows, (const int*)latch,
+                      (const T*)q_st, (const T*)qd_st, (const T*)avg_st, (T*)q_io, (T*)qdot_io, (T*)avg_vel_out);
       };
       if (lo) return go(mrf::k_rollout_peer<T, LS, true>);
       return go(mrf::k_rollout_peer<T, LS, false>);
@@ -674,7 +745,11 @@ int mrf_comm_reset(mrf_handle* h) {
     // call is the usual reason for the timeout).  The caller's barriers on both sides keep peers from writing meanwhile.
     if (int rc = check_hip(h, hipMemset(c->local + c->off_flags, 0, c->off_x - c->off_flags), "hipMemset")) return rc;
     if (int rc = check_hip(h, hipDeviceSynchronize(), "hipDeviceSynchronize")) return rc;
-    c->seq = 1;
+    // A peer whose stream was still running when this rank cleared its flags may have stored a flag of the OLD
+    // sequence afterwards.  Sequence numbers carry the reset count in their high bits, so such a flag is smaller than
+    // every number of the restarted sequence and can satisfy none of its waits.
+    c->epoch += 1;
+    c->seq = (c->epoch << 40) | 1ull;
   }
   return MRF_OK;
 }

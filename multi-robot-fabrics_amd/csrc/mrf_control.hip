@@ -40,6 +40,61 @@ __global__ __launch_bounds__(64) void k_control_prepare(const DevCfg<T>* __restr
   }
 }
 
+
+// Obstacle assembly of the Cartesian rollouts on the device (compute_x_obsts_dyn_0, utils_fabrics_kinematics.py:3-33;
+// EXC:330-352): the dynamic obstacles of robot i are the configured spheres of all OTHER robots of its scenario, at
+// their current positions, with their current velocities J qdot (zero for static fabrics), in increasing robot order.
+// One lane walks one (scenario, robot) chain and scatters each of its spheres into the obstacle arrays
+// [M][3][rows] / [M][rows] of the N - 1 other rows of the scenario (M = S (N - 1)).
+template <typename T>
+__global__ __launch_bounds__(64) void k_publish_obstacles(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
+                                                           const T* __restrict__ q, const T* __restrict__ qd,
+                                                           T* __restrict__ ox, T* __restrict__ ov, T* __restrict__ orad) {
+  __shared__ T xch[21 * 64];
+  const DevCfg<T>& cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int N = cfg.n_robots, S = cfg.n_spheres;
+  const int64_t rows = n_scen * N;
+  int64_t r = (int64_t)blockIdx.x * 64 + lane;
+  const bool active = r < rows;
+  if (!active) r = rows - 1;
+  const int64_t scen = r / N;
+  const int j = (int)(r - scen * N);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    T s, c;
+    m_sincos(q[k * rows + r], &s, &c);
+    xch[(3 * k + 0) * 64 + lane] = c;
+    xch[(3 * k + 1) * 64 + lane] = s;
+    xch[(3 * k + 2) * 64 + lane] = qd[k * rows + r];
+  }
+  __syncthreads();
+  const bool dyn = cfg.dynamic != 0;
+  panda_walk_spheres<false, T>(
+      cfg, cfg.mount[j],
+      [&](int k, T& c, T& s, T& qdk) {
+        c = xch[(3 * k + 0) * 64 + lane];
+        s = xch[(3 * k + 1) * 64 + lane];
+        qdk = xch[(3 * k + 2) * 64 + lane];
+      },
+      [&](int s, const T* x, const T* v, const T*) {
+        if (!active) return;
+        const T rad = cfg.sphere_r[s];
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          if (i == j) continue;
+          const int m = (j < i ? j : j - 1) * S + s;  // position of robot j among the others of robot i
+          const int64_t row_i = scen * N + i;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            ox[(int64_t)(m * 3 + c) * rows + row_i] = x[c];
+            ov[(int64_t)(m * 3 + c) * rows + row_i] = dyn ? v[c] : T(0);
+          }
+          orad[(int64_t)m * rows + row_i] = rad;
+        }
+      });
+}
+
 template <typename T>
 struct DeadlockCfg {
   T avg_vel_constant, dist_constant, w_follower, w_leader, goal_scale, ee_distance, follower_offset, min_goal_norm, z_floor;
@@ -538,6 +593,75 @@ int mrf_apply_action(mrf_handle* h, int64_t rows, void* q_io, void* qdot_io, voi
   });
 }
 
+
+}  // extern "C"
+
+namespace mrf_host {
+void cart_work_release(mrf_handle* h) {
+  if (h->cart_work) (void)hipFree(h->cart_work);
+  h->cart_work = nullptr;
+  h->cart_work_bytes = 0;
+}
+}  // namespace mrf_host
+
+namespace {
+size_t cart_work_need(const mrf_handle* h, int64_t n_scen) {
+  const size_t sb = h->cfg.scalar == MRF_F64 ? 8 : 4;
+  const size_t rows = (size_t)n_scen * h->cfg.n_robots, M = (size_t)h->cfg.n_spheres * (h->cfg.n_robots - 1);
+  return sb * 7 * M * rows;  // x [M][3][rows], v [M][3][rows], radius [M][rows]
+}
+int cart_work_ensure(mrf_handle* h, int64_t n_scen) {
+  const size_t need = cart_work_need(h, n_scen);
+  if (need <= h->cart_work_bytes) return MRF_OK;
+  mrf_host::cart_work_release(h);
+  if (int rc = check_hip(h, hipMalloc(&h->cart_work, need), "hipMalloc (Cartesian rollout obstacles)")) return rc;
+  h->cart_work_bytes = need;
+  return MRF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
+                                  void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+  MRF_CHECK_READY(h);
+  if (int rc = need_panda_vel(h, "rollout_cartesian_coupled")) return rc;
+  if (n_scen == 0) return MRF_OK;
+  if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
+  const int N = h->cfg.n_robots, S = h->cfg.n_spheres;
+  const int64_t rows = n_scen * N;
+  const int M = S * (N - 1);
+  if (M == 0) return mrf_rollout_cartesian(h, rows, q0, qdot0, params, 0, 0, nullptr, nullptr, nullptr, nullptr, avg_out, traj_q, traj_qd, stream);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+  if (cart_work_need(h, n_scen) > h->cart_work_bytes) {
+    if (cap != hipStreamCaptureStatusNone)
+      return fail(h, MRF_E_ARG, "rollout_cartesian_coupled: work buffer too small inside a stream capture (run once outside first)");
+    if (int rc = cart_work_ensure(h, n_scen)) return rc;
+  }
+  const size_t sb = h->cfg.scalar == MRF_F64 ? 8 : 4;
+  char* ox = (char*)h->cart_work;
+  char* ov = ox + sb * 3 * (size_t)M * rows;
+  char* orad = ov + sb * 3 * (size_t)M * rows;
+  dim3 block(64), grid((unsigned)((rows + 63) / 64));
+  int rc = dispatch_scalar(h, [&](auto t) {
+    using T = decltype(t);
+    return launch(h, mrf::k_publish_obstacles<T>, grid, block, (hipStream_t)stream, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
+                  (const T*)q0, (const T*)qdot0, (T*)ox, (T*)ov, (T*)orad);
+  });
+  if (rc) return rc;
+  // zero obstacle accelerations: FPC:33 presets them and the drivers never change that (obst_a = NULL kernel)
+  return mrf_rollout_cartesian(h, rows, q0, qdot0, params, M, 0, ox, ov, nullptr, orad, avg_out, traj_q, traj_qd, stream);
+}
+
+int mrf_episode_set_rollout(mrf_handle* h_rollout, int32_t kind) {
+  MRF_CHECK_READY(h_rollout);
+  if (kind != MRF_ROLLOUT_JOINTSPACE && kind != MRF_ROLLOUT_CARTESIAN) return fail(h_rollout, MRF_E_ARG, "unknown rollout kind");
+  h_rollout->episode_rollout_kind = kind;
+  return MRF_OK;
+}
+
+
 static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mrf_deadlock_config* dl, int apply_estimate,
                         const double* vel_limit, double stop_margin, void* q, void* qd, const void* prm_nom,
                         void* prm_work, const int32_t* sm, int32_t* dl_state, void* dl_goal, void* x_ee, void* avg,
@@ -558,7 +682,10 @@ static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mr
     }
   }
   if (hr) {
-    if ((rc = mrf_rollout(hr, n_scen, q, qd, prm_work, avg, nullptr, nullptr, st))) return rc;
+    rc = hr->episode_rollout_kind == MRF_ROLLOUT_CARTESIAN
+             ? mrf_rollout_cartesian_coupled(hr, n_scen, q, qd, prm_work, avg, nullptr, nullptr, st)
+             : mrf_rollout(hr, n_scen, q, qd, prm_work, avg, nullptr, nullptr, st);
+    if (rc) return rc;
     if (dl && (rc = mrf_deadlock_step(hr, n_scen, dl, -1, x_ee, avg, sm, prm_work, dl_state, dl_goal, st))) return rc;
   }
   if ((rc = mrf_compute_action_coupled(ha, n_scen, q, qd, (hr || pp.on) ? prm_work : prm_nom, 0, nullptr, act, st))) return rc;
@@ -601,6 +728,12 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
     if (rc && hr && ha->err.empty()) ha->err = hr->err;
     return rc;
   };
+  if (hr && hr->episode_rollout_kind == MRF_ROLLOUT_CARTESIAN && hr->cfg.n_robots > 1 && hr->cfg.n_spheres > 0) {
+    if (int rc = cart_work_ensure(hr, n_scen)) {  // outside any capture: the captured step must not allocate
+      if (ha->err.empty()) ha->err = hr->err;
+      return rc;
+    }
+  }
   if (!use_graph) {
     for (int k = 0; k < n_steps; ++k)
       if (int rc = one(stream)) return rc;
@@ -624,7 +757,8 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
   // what the captured launches bake in besides the arguments: the handles' constants (a destroyed handle's address
   // can be handed to a new one: the creation serial tells them apart), and the kernel variant chosen from the config
   const uint64_t ident[] = {ha->serial, hr ? hr->serial : 0, (uint64_t)(uintptr_t)ha->dcfg,
-                            (uint64_t)(uintptr_t)(hr ? hr->dcfg : nullptr)};
+                            (uint64_t)(uintptr_t)(hr ? hr->dcfg : nullptr), (uint64_t)(hr ? hr->episode_rollout_kind : 0),
+                            (uint64_t)(uintptr_t)(hr ? hr->cart_work : nullptr)};
   key.append((const char*)ident, sizeof(ident));
   key.append((const char*)&ha->pp, sizeof(ha->pp));  // attached pick-and-place buffers and constants
   key.append((const char*)&dlc, sizeof(dlc));

@@ -752,6 +752,46 @@ struct PrmView {
   }
 };
 
+// Row addressing for the kernels whose rows are (first row of the block) + lane: every array element a[c*rows + row]
+// is read as  (a + c*rows + first)  [off]  -- a wave-uniform pointer that lives in an SGPR pair and is advanced with scalar
+// arithmetic, plus ONE 32-bit lane offset shared by all accesses of the kernel (global_load ... v_off, s[base:base+1]).
+// The per-lane 64-bit form (a + row, kept in a VGPR pair per array across the whole step loop) is what put the loop
+// invariants of the Cartesian rollout into scratch memory.
+template <typename T>
+struct RowAddr {
+  int64_t rows;   // wave-uniform
+  int64_t first;  // wave-uniform: first row of this block
+  uint32_t off;   // this lane's row - first (tail lanes clamped onto the last valid row)
+  __device__ __forceinline__ const T* at(const T* __restrict__ a, int64_t comp) const { return a + comp * rows + first; }
+  __device__ __forceinline__ T* at(T* __restrict__ a, int64_t comp) const { return a + comp * rows + first; }
+  __device__ __forceinline__ T load(const T* __restrict__ a, int64_t comp) const { return at(a, comp)[off]; }
+  __device__ __forceinline__ void store(T* __restrict__ a, int64_t comp, T v) const { at(a, comp)[off] = v; }
+};
+
+// PrmView over RowAddr (same interface; used by k_rollout_cart_panda)
+template <typename T>
+struct PrmViewU {
+  const T* __restrict__ base;
+  RowAddr<T> ra;
+  T g0[3];
+  bool own_goal;
+  __device__ __forceinline__ T operator[](int i) const {
+    if (i < 3 && own_goal) return i == 0 ? g0[0] : (i == 1 ? g0[1] : g0[2]);
+    return ra.load(base, i);
+  }
+};
+
+// a wave-uniform value computed by vector instructions, moved to an SGPR pair (frees the VGPR pair it would occupy
+// across a loop; VOP3 reads it as a scalar operand)
+__device__ __forceinline__ double to_uniform(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float to_uniform(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+
 template <typename T>
 struct PandaState {
   T q[7], qd[7], cq[7], sq[7];

@@ -35,6 +35,11 @@ struct mrf_handle {
     uint64_t grasp_serial = 0;
     void* action_grasp = nullptr;
   } pp;
+  // mrf_rollout_cartesian_coupled (mrf_control.hip): obstacle arrays assembled on the device, grown on demand (never
+  // inside a stream capture: mrf_episode_run sizes them before it captures)
+  void* cart_work = nullptr;
+  size_t cart_work_bytes = 0;
+  int episode_rollout_kind = 0;  // mrf_episode_set_rollout: which rollout an episode on this ROLLOUT handle runs
   void* staging = nullptr;  // pinned + device staging buffers and the stream of the host-buffer entry points (mrf_hostpath.hip)
   void* comm = nullptr;   // robot-sharded rollout state (mrf_comm.hip): communicator / mapped peer buffers / work buffers
 };
@@ -73,9 +78,17 @@ int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args.
   return check_hip(h, hipGetLastError(), "kernel launch");
 }
 
+// -DMRF_DEV_F64_PANDA_ONLY (development builds, tools/build_variant.sh): only the float64 / reference-leaf-set
+// instantiations are compiled (a quarter of the compile time when iterating on one kernel's ISA); any other
+// configuration then fails loudly instead of running.
 template <typename F>
 int dispatch_scalar(mrf_handle* h, F f) {
+#ifdef MRF_DEV_F64_PANDA_ONLY
+  if (h->cfg.scalar != MRF_F64) return fail(h, MRF_E_CONFIG, "development build: float64 only");
+  return f(double{});
+#else
   return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
+#endif
 }
 
 
@@ -111,8 +124,13 @@ inline bool is_link_origin_table(const mrf_config& c) {
 template <typename F>
 int dispatch(mrf_handle* h, F f) {  // f(scalar tag, leaf-set tag)
   const bool fast = is_panda_leafset(h->cfg);
+#ifdef MRF_DEV_F64_PANDA_ONLY
+  if (h->cfg.scalar != MRF_F64 || !fast) return fail(h, MRF_E_CONFIG, "development build: float64, reference leaf set only");
+  return f(double{}, LeafSetPanda{});
+#else
   if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafSetPanda{}) : f(double{}, LeafSetGeneric{});
   return fast ? f(float{}, LeafSetPanda{}) : f(float{}, LeafSetGeneric{});
+#endif
 }
 
 // mrf_step_action with an explicit robot -> block-position map of sph_all (padded all-gather layouts); NULL = identity
@@ -123,6 +141,8 @@ int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_
 void comm_release(mrf_handle* h);
 // frees h->staging (mrf_hostpath.hip); called by mrf_destroy
 void staging_release(mrf_handle* h);
+// frees h->cart_work (mrf_control.hip); called by mrf_destroy
+void cart_work_release(mrf_handle* h);
 
 }  // namespace mrf_host
 

@@ -69,28 +69,20 @@ constexpr bool kCartSingleWalk = true;
 // obstacle loop over HBM arrays [n_obst][3][rows] (compute_action / Cartesian rollout); tk = elapsed obstacle time
 // ACC = false: the caller passes no obstacle accelerations (oa == NULL -- what the reference's drivers do,
 // FPC:33, EXJ:411): the three acceleration loads per obstacle and the n.a_o term of every leaf are compiled out.
-template <class CL, bool ACC = true, typename T>
-__device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int64_t rows, int64_t r, int n_obst,
+// ADDR: how a lane finds its element of component `comp`: LaneAddr (a[comp*rows + row], per-lane 64-bit addresses) or
+// RowAddr (wave-uniform base + 32-bit lane offset, mrf_device.hpp).
+template <typename T>
+struct LaneAddr {
+  int64_t rows, r;
+  __device__ __forceinline__ T load(const T* __restrict__ a, int64_t comp) const { return a[comp * rows + r]; }
+};
+
+template <class CL, bool ACC = true, typename T, class ADDR>
+__device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, const ADDR& addr, int n_obst,
                                                       int n_static, const T* __restrict__ ox, const T* __restrict__ ov,
                                                       const T* __restrict__ oa, const T* __restrict__ orad, T tk,
                                                       bool allow_planar, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc,
                                                       int m_first = 0) {  // obstacles [m_first, n_obst)
-#ifdef MRF_NO_ARRAY_PREFETCH
-#pragma unroll 1
-  for (int m = m_first; m < n_obst; ++m) {
-    const bool is_static = m < n_static;  // static leaves: full 3-D distance, no reference motion
-    T xo[3], vo[3], ao[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int64_t idx = (int64_t)(m * 3 + c) * rows + r;
-      vo[c] = (ov && !is_static) ? ov[idx] : T(0);
-      xo[c] = ox[idx] + tk * vo[c];  // Cartesian rollout: x += dt*v per step (FPC:448-453); tk = 0 otherwise
-      ao[c] = (oa && !is_static) ? oa[idx] : T(0);
-    }
-    accumulate_obstacle<CL>(cfg, E, xo, vo, ao, orad[(int64_t)m * rows + r],
-                            allow_planar && !is_static && cfg.obst_dim == 2, acc);
-  }
-#else
   // buf: x[3], v[3], a[3], radius.  Missing arrays (NULL) and static obstacles read x in their place and are zeroed in
   // the fold, so that the fetch is the same ten loads for every obstacle (no divergent address arithmetic).
   const T* pv = ov ? ov : ox;
@@ -100,14 +92,13 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
       n_obst - m_first,
       [&](int mi, T (&buf)[NV]) {
         const int m = mi + m_first;
-        const int64_t base = (int64_t)(m * 3) * rows + r;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          buf[c] = ox[base + c * rows];
-          buf[3 + c] = pv[base + c * rows];
-          if constexpr (ACC) buf[6 + c] = pa[base + c * rows];
+          buf[c] = addr.load(ox, m * 3 + c);
+          buf[3 + c] = addr.load(pv, m * 3 + c);
+          if constexpr (ACC) buf[6 + c] = addr.load(pa, m * 3 + c);
         }
-        buf[NV - 1] = orad[(int64_t)m * rows + r];
+        buf[NV - 1] = addr.load(orad, m);
       },
       [&](int mi, T (&buf)[NV]) {
         const int m = mi + m_first;
@@ -129,7 +120,6 @@ __device__ __forceinline__ void obstacles_from_arrays(const DevCfg<T>& cfg, int6
         accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], allow_planar && !is_static && cfg.obst_dim == 2, acc);
 #endif
       });
-#endif
 }
 
 // The Cartesian rollout passes over the same obstacle set H times (x0, v, a, r are constants of the rollout; only the
@@ -195,10 +185,10 @@ __device__ __forceinline__ void obstacles_resident(const DevCfg<T>& cfg, const T
 
 // One pipelined loop over ALL obstacles of a row: the first nres come from the resident LDS tile, the rest from the HBM
 // arrays (wave-uniform switch inside the fetch).  A single loop keeps one pair of ping-pong buffers and two inlined copies
-// of the five-point fold alive instead of two loops with four.
+// of the five-point fold alive instead of two loops with four.  Streamed loads use RowAddr (uniform base + lane offset).
 template <class CL, bool ACC, typename T>
 __device__ __forceinline__ void obstacles_cart(const DevCfg<T>& cfg, const T* __restrict__ res, int lane, int nres,
-                                               int64_t rows, int64_t r, int n_obst, int n_static,
+                                               const RowAddr<T>& ra, int n_obst, int n_static,
                                                const T* __restrict__ ox, const T* __restrict__ ov,
                                                const T* __restrict__ oa, const T* __restrict__ orad, T tk,
                                                const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
@@ -215,14 +205,13 @@ __device__ __forceinline__ void obstacles_cart(const DevCfg<T>& cfg, const T* __
 #pragma unroll
           for (int c = 0; c < NV; ++c) buf[c] = src[c * 64];
         } else {
-          const int64_t base = (int64_t)(m * 3) * rows + r;
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            buf[c] = ox[base + c * rows];
-            buf[3 + c] = pv[base + c * rows];
-            if constexpr (ACC) buf[6 + c] = pa[base + c * rows];
+            buf[c] = ra.load(ox, m * 3 + c);
+            buf[3 + c] = ra.load(pv, m * 3 + c);
+            if constexpr (ACC) buf[6 + c] = ra.load(pa, m * 3 + c);
           }
-          buf[NV - 1] = orad[(int64_t)m * rows + r];
+          buf[NV - 1] = ra.load(orad, m);
         }
       },
       [&](int m, T (&buf)[NV]) {
@@ -240,66 +229,6 @@ __device__ __forceinline__ void obstacles_cart(const DevCfg<T>& cfg, const T* __
         }
         accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
       });
-}
-
-// Interleaved form: iteration k folds streamed obstacle k (HBM / Infinity Cache) and resident obstacle k (LDS).  The
-// load of streamed obstacle k+1 is issued BEFORE both folds, i.e. it has two folds (~2 200 cycles, ~1 us) to arrive
-// instead of one -- a single wave per SIMD has nothing else to hide that latency with -- at the price of one more
-// buffer (two streamed + one resident) and a register copy of the streamed buffer per iteration.
-template <class CL, bool ACC, typename T>
-__device__ __forceinline__ void obstacles_cart_interleaved(const DevCfg<T>& cfg, const T* __restrict__ res, int lane,
-                                                           int nres, int64_t rows, int64_t r, int n_obst, int n_static,
-                                                           const T* __restrict__ ox, const T* __restrict__ ov,
-                                                           const T* __restrict__ oa, const T* __restrict__ orad, T tk,
-                                                           const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-  typedef const __attribute__((address_space(3))) T* lds_ptr;
-  constexpr int NV = ACC ? 10 : 7;
-  const T* pv = ov ? ov : ox;
-  const T* pa = oa ? oa : ox;
-  const bool any_v = ov != nullptr, any_a = ACC && oa != nullptr;
-  const int nS = n_obst - nres, nR = nres, K = nS > nR ? nS : nR;
-  auto fetch_stream = [&](int k, T (&buf)[NV]) {
-    const int m = nres + k;
-    const int64_t base = (int64_t)(m * 3) * rows + r;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      buf[c] = ox[base + c * rows];
-      buf[3 + c] = pv[base + c * rows];
-      if constexpr (ACC) buf[6 + c] = pa[base + c * rows];
-    }
-    buf[NV - 1] = orad[(int64_t)m * rows + r];
-  };
-  auto fetch_resident = [&](int k, T (&buf)[NV]) {
-    lds_ptr src = (lds_ptr)(res + k * (NV * 64) + lane);
-#pragma unroll
-    for (int c = 0; c < NV; ++c) buf[c] = src[c * 64];
-  };
-  auto fold = [&](int m, T (&buf)[NV]) {
-    const bool is_static = m < n_static;
-    const bool has_v = any_v && !is_static, has_a = any_a && !is_static;
-    T xo[3], vo[3], ao[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      vo[c] = has_v ? buf[3 + c] : T(0);
-      xo[c] = buf[c] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
-      if constexpr (ACC)
-        ao[c] = has_a ? buf[6 + c] : T(0);
-      else
-        ao[c] = T(0);
-    }
-    accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
-  };
-  T Sa[NV], Sb[NV], Rb[NV];
-  if (nS > 0) fetch_stream(0, Sa);
-#pragma unroll 1
-  for (int k = 0; k < K; ++k) {
-    if (k + 1 < nS) fetch_stream(k + 1, Sb);
-    if (k < nR) fetch_resident(k, Rb);
-    if (k < nS) fold(nres + k, Sa);
-    if (k < nR) fold(k, Rb);
-#pragma unroll
-    for (int c = 0; c < NV; ++c) Sa[c] = Sb[c];
-  }
 }
 
 // ---------------------------------------------------------------------------- compute_action
@@ -320,8 +249,8 @@ __global__ __launch_bounds__(256) MRF_ATTR_ACTION void k_action_panda(const DevC
   panda_solve_row<LS, kActionSingleWalk>(
       cfg, cfg.mount[(int)(r % cfg.n_robots)], R, P,
       [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-        obstacles_from_arrays<typename LS::Collision, ACC>(cfg, rows, r, n_obst, n_static, ox, ov, oa, orad, T(0), false, E,
-                                                           acc);
+        obstacles_from_arrays<typename LS::Collision, ACC>(cfg, LaneAddr<T>{rows, r}, n_obst, n_static, ox, ov, oa, orad, T(0),
+                                                           false, E, acc);
       },
       qdd, act);
 #pragma unroll
@@ -559,20 +488,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
                                                        T* __restrict__ traj_q, T* __restrict__ traj_qd) {
   __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
-#ifdef MRF_EXP_LDSCFG
-  // experiment (VERDICT r2 next-4 ii): the planner constants staged in LDS once per block, so that the step loop reads
-  // them with ds_read (counted, in-order lgkmcnt) instead of scalar loads behind s_waitcnt lgkmcnt(0)
-  __shared__ DevCfg<T> scfg;
-  {
-    const int* src = reinterpret_cast<const int*>(cfgp);
-    int* dst = reinterpret_cast<int*>(&scfg);
-    for (int w = threadIdx.x; w < (int)(sizeof(DevCfg<T>) / 4); w += 64) dst[w] = src[w];
-    __syncthreads();
-  }
-  const DevCfg<T>& cfg = scfg;
-#else
   const DevCfg<T>& cfg = *cfgp;
-#endif
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
   const int spw = 64 / N;  // scenarios per wave
@@ -1019,6 +935,9 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
 // ---------------------------------------------------------------------------- Cartesian rollout
 // RES: the first CART_RESIDENT<T> obstacles live in LDS for the whole rollout (one wave per block); RES = false is the
 // plain streaming form with 256-thread blocks (switch -DMRF_CART_STREAM_ONLY, A/B by tools/prof_kernels.py).
+// Every global access of the step loop goes through RowAddr: wave-uniform bases in SGPRs + one shared lane offset, and
+// the elapsed obstacle time is a scalar -- the loop invariants that used to sit in VGPR pairs (and, beyond 512 registers,
+// in scratch memory) are gone from the vector file.
 template <typename T, class LS, bool RES, bool ACC>
 __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
@@ -1027,23 +946,43 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
                                                              const T* __restrict__ oa, const T* __restrict__ orad,
                                                              T* __restrict__ avg_out, T* __restrict__ traj_q,
                                                              T* __restrict__ traj_qd) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = r < rows;  // the tail lanes shadow the last row (wave-wide votes below), without stores
-  if (!active) r = rows - 1;
+  // rows of this block: first .. first + blockDim - 1; the tail lanes shadow the last row (wave-wide votes below),
+  // without stores
+  RowAddr<T> ra;
+  ra.rows = rows;
+  ra.first = (int64_t)blockIdx.x * blockDim.x;
+  const int64_t left = rows - ra.first;  // >= 1
+  const bool active = (int64_t)threadIdx.x < left;
+  ra.off = active ? threadIdx.x : (uint32_t)(left - 1);
+  const int64_t r = ra.first + ra.off;
   const DevCfg<T>& cfg = *cfgp;
   PandaState<T> R;
   load_state(rows, r, q0, qd0, R);
-  PrmView<T> P{prm, rows, r, {T(0), T(0), T(0)}, false};
-  const T* mount_own = cfg.mount[(int)(r % cfg.n_robots)];
+  PrmViewU<T> P{prm, ra, {T(0), T(0), T(0)}, false};
+  const int li = (int)(r % cfg.n_robots);
+#ifdef MRF_CART_MOUNT_LDS
+  // experiment (profiles/r04_experiments.json): the mount transform is a per-lane loop invariant (12 values, and with it
+  // joint 1's axis and origin); staged in LDS once and re-read in every step through an index the optimizer cannot hoist
+  __shared__ T mnt[MRF_MAX_ROBOTS * 12];
+  for (int w = threadIdx.x; w < cfg.n_robots * 12; w += blockDim.x) mnt[w] = cfg.mount[w / 12][w % 12];
+#else
+  const T* mount_own = cfg.mount[li];
+#endif
   constexpr int NRES = CART_RESIDENT<T, ACC>;
   __shared__ T res[RES ? NRES * (ACC ? 10 : 7) * 64 : 1];
   const int nres = RES ? (n_obst < NRES ? n_obst : NRES) : 0;
   if constexpr (RES) stage_resident_obstacles<ACC>(res, (int)threadIdx.x, nres, rows, r, ox0, ov, oa, orad);
+  __syncthreads();
   T sumsq = T(0);
-  T tk = T(0);  // elapsed obstacle time k*dt
   const int H = cfg.horizon;
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
+    const T tk = to_uniform((T)k * cfg.dt);  // elapsed obstacle time (FPC:448-453: x += dt*v per step)
+#ifdef MRF_CART_MOUNT_LDS
+    int li_k = li;
+    asm volatile("" : "+v"(li_k));
+    const T* mount_own = mnt + li_k * 12;
+#endif
     T qdd[7], act[7];
     panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
@@ -1060,19 +999,14 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
           if constexpr (RES && two_loops) {
             obstacles_resident<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, n_static, ov != nullptr,
                                                             oa != nullptr, tk, E, acc);
-            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false,
-                                                               E, acc, nres);
-#ifdef MRF_CART_INTERLEAVED
+            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, ra, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
+                                                               nres);
           } else if constexpr (RES) {
-            obstacles_cart_interleaved<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, rows, r, n_obst, n_static,
-                                                                    ox0, ov, oa, orad, tk, E, acc);
-#endif
-          } else if constexpr (RES) {
-            obstacles_cart<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, rows, r, n_obst, n_static, ox0, ov,
-                                                        oa, orad, tk, E, acc);
+            obstacles_cart<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, ra, n_obst, n_static, ox0, ov, oa,
+                                                        orad, tk, E, acc);
           } else {
-            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, rows, r, n_obst, n_static, ox0, ov, oa, orad, tk, false,
-                                                               E, acc, 0);
+            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, ra, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
+                                                               0);
           }
         },
         qdd, act);
@@ -1108,15 +1042,14 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
     }
     if (active && traj_q) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) traj_q[((int64_t)k * 7 + j) * rows + r] = R.q[j];
+      for (int j = 0; j < 7; ++j) ra.store(traj_q, (int64_t)k * 7 + j, R.q[j]);
     }
     if (active && traj_qd) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) traj_qd[((int64_t)k * 7 + j) * rows + r] = R.qd[j];
+      for (int j = 0; j < 7; ++j) ra.store(traj_qd, (int64_t)k * 7 + j, R.qd[j]);
     }
-    tk += cfg.dt;
   }
-  if (active) avg_out[r] = sumsq / (T)(H * 7);
+  if (active) ra.store(avg_out, 0, sumsq / (T)(H * 7));
 }
 
 // ---------------------------------------------------------------------------- sphere kinematics
@@ -1547,6 +1480,7 @@ void mrf_destroy(mrf_handle* h) {
   mrf_host::DeviceGuard guard(h->dcfg ? h->device : -1);
   mrf_host::comm_release(h);
   mrf_host::staging_release(h);
+  mrf_host::cart_work_release(h);
   if (h->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)h->graph_exec);
   if (h->own_stream) (void)hipStreamDestroy((hipStream_t)h->own_stream);
   if (h->dcfg) (void)hipFree(h->dcfg);

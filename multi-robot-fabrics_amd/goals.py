@@ -1,5 +1,7 @@
 """Minimal mirror of mpscenes' GoalComposition as the reference uses it (example_pandas_Jointspace.py:25-62,
 361-365; example_pointmasses_static.py:61-83): a named dict of sub-goals with attribute access."""
+import math
+
 import numpy as np
 
 
@@ -66,3 +68,18 @@ class GoalComposition:
             if g.is_primary_goal():
                 return g
         return self._sub_goals[0]
+
+
+def panda_pick_place_goal(orientation_weight=10.0):
+    """The three-part goal of the Panda drivers (EXJ:25-62 / EXC:24-61; the Cartesian driver weighs the orientation
+    part 20): hand position in the world, hand axis relative to link 7 (the 0.107 m offset of the flange), joint 7
+    angle.  Every number here is a placeholder: positions, weights and the rotation are runtime parameters."""
+    hand = dict(indices=[0, 1, 2], child_link="panda_hand", epsilon=0.05, type="staticSubGoal")
+    parts = [
+        dict(hand, weight=2.0, is_primary_goal=True, parent_link="world", desired_position=[0.1, 0.6, 0.8]),
+        dict(hand, weight=float(orientation_weight), is_primary_goal=False, parent_link="panda_link7",
+             desired_position=[0.107, 0.0, 0.0], angle=[-0.366, 0.0, 0.0, 0.3305]),
+        dict(weight=1.0, is_primary_goal=False, indices=[6], desired_position=[math.pi / 4], epsilon=0.05,
+             type="staticJointSpaceSubGoal"),
+    ]
+    return GoalComposition(name="goal", content_dict={"subgoal%d" % k: part for k, part in enumerate(parts)})

@@ -101,6 +101,21 @@ class manipulator_parameters:
         return [self.ROLLOUT_FABRICS, self.ROLLOUTS_PLOTTING, self.STATIC_OR_DYN_FABRICS, self.RESOLVE_DEADLOCKS,
                 self.ESTIMATE_GOAL, self.N_HORIZON, self.MPC_LAYER]
 
+    def obstacle_counts(self, i_robot):
+        """(static, dynamic) obstacle spheres the MAIN planner of robot i is built for: every sphere of the other robots
+        (n_obst_per_link on each of their eight links), static or moving by STATIC_OR_DYN_FABRICS."""
+        n = self.nr_obsts_dyn_all[i_robot]
+        return (0, n) if self.STATIC_OR_DYN_FABRICS else (n, 0)
+
+    def rollout_planner_spec(self, i_robot):
+        """(dof, static, dynamic, collision links) of robot i's ROLLOUT planner: it sees one sphere per link of the other
+        robots -- their link origins, nr_obsts_dyn -- whatever n_obst_per_link the main planners use."""
+        return self.dof[i_robot], self.nr_obsts[i_robot], self.nr_obsts_dyn[i_robot], self.collision_links_nrs[i_robot]
+
+    def apply_yaml(self, setup):
+        """define_settings from a loaded panda_config.yaml (its n_robots key belongs to the constructor)."""
+        return self.define_settings(**{k: v for k, v in setup.items() if k != "n_robots"})
+
     def set_horizon(self, n_horizon):
         self.N_HORIZON = n_horizon
 
@@ -108,14 +123,20 @@ class manipulator_parameters:
         return copy.deepcopy(self)
 
 
-def load_yaml_settings(path):
-    """The eight keys of examples/configs/panda_config.yaml -> (manipulator_parameters, settings dict)."""
+def read_yaml(path=None):
+    """The eight keys of examples/configs/panda_config.yaml as a dict (path None: the shipped file)."""
     import yaml
+    if path is None:
+        path = os.path.join(os.path.dirname(_URDF_DIR), os.pardir, "configs", "panda_config.yaml")
     with open(path, "r") as f:
-        setup = yaml.safe_load(f)
+        return yaml.safe_load(f)
+
+
+def load_yaml_settings(path=None, apply_flags=True):
+    """-> (manipulator_parameters, settings dict); apply_flags=False leaves the flags at the constructor's values (the
+    joint-space driver builds its main planners in that state)."""
+    setup = read_yaml(path)
     p = manipulator_parameters(nr_robots=setup["n_robots"], n_obst_per_link=setup["n_obst_per_link"])
-    p.define_settings(ROLLOUT_FABRICS=setup["ROLLOUT_FABRICS"], ROLLOUTS_PLOTTING=setup["ROLLOUTS_PLOTTING"],
-                      STATIC_OR_DYN_FABRICS=setup["STATIC_OR_DYN_FABRICS"], RESOLVE_DEADLOCKS=setup["RESOLVE_DEADLOCKS"],
-                      ESTIMATE_GOAL=setup["ESTIMATE_GOAL"], N_HORIZON=setup["N_HORIZON"],
-                      n_obst_per_link=setup["n_obst_per_link"])
+    if apply_flags:
+        p.apply_yaml(setup)
     return p, setup

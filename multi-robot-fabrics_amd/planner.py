@@ -330,3 +330,21 @@ class ParameterizedFabricPlanner:
 
     def get_leaves(self, leaf_names):
         return [self.leaves[name] for name in leaf_names]
+
+
+def panda_planner(urdf_path, mount, goal, link_numbers, n_static, n_dynamic, dt=0.01, device=None, **strings):
+    """One concretized Panda planner as the example drivers configure it: chain read from `urdf_path` (and checked against
+    the compiled one), mounted at the 4x4 `mount`, collision + table-plane leaves on `link_numbers` (numbers above 8 mean
+    the hand), joint-limit leaves, `goal`, velocity output with time step dt.  Leaf strings default to the drivers'
+    (config.PANDA_STRINGS = EXJ:87-89)."""
+    with open(urdf_path, "r") as f:
+        fk = GenericURDFFk(f.read(), "panda_link0", "panda_leftfinger")
+    fk.set_mount_transformation(np.asarray(mount, dtype=float))
+    planner = ParameterizedFabricPlanner(7, fk, **dict(_config.PANDA_STRINGS, **strings))
+    if device is not None:
+        planner.device = device
+    names = ["panda_hand" if int(l) > 8 else "panda_link%d" % int(l) for l in link_numbers]
+    planner.set_components(collision_links=names, goal=goal, number_obstacles=int(n_static), number_dynamic_obstacles=int(n_dynamic),
+                           dynamic_obstacle_dimension=3, number_plane_constraints=1, limits=_config.PANDA_LIMITS)
+    planner.concretize(mode="vel", time_step=dt)
+    return planner

@@ -72,6 +72,13 @@ class ForwardFabricsPlanner:
         self._handle = None
 
     # -- construction ------------------------------------------------------------------------------------------
+    @classmethod
+    def for_cell(cls, params, planner_of, goals, n_steps=100, fk_dict=None, **kw):
+        """Rollout object of a whole cell, ready to use: planner_of(i) -> the rollout planner of robot i."""
+        rollout = cls(params, [planner_of(i) for i in range(params.nr_robots)], n_steps, fk_dict, goals, **kw)
+        rollout.forward_multi_fabrics_symbolic()
+        return rollout
+
     def forward_multi_fabrics_symbolic(self):
         if self.fabrics_mode != "vel":
             raise NotImplementedError("the joint-space rollout is defined for fabrics_mode 'vel' only (FPJ:233)")
@@ -212,6 +219,20 @@ class FabricsRollouts:
         self.constraints = constraints
         self.radius_body_panda_links = {str(l): np.array(radius_sphere) for l in self.collision_links_nrs if l > 2}
         self._handle = None
+
+    @classmethod
+    def for_robot(cls, params, i_robot, planner, goal):
+        """The rollout object of robot i as the Cartesian driver sets it up (EXC:172-192): horizon params.N_HORIZON, all
+        spheres of the other robots as constant-velocity obstacles, bound to `planner`."""
+        dof = params.dof[i_robot]
+        n_dyn = params.nr_obsts_dyn_all[i_robot]
+        r = cls(params.N_HORIZON, params.dt, 2 * dof, dof, dof, params.nr_obsts[i_robot], False, nr_obsts_dyn=n_dyn,
+                v_obsts_dyn=[np.zeros(3)] * n_dyn, fabrics_mode=params.fabrics_mode,
+                collision_links_nrs=params.collision_links_nrs[i_robot], nr_constraints=params.nr_constraints[i_robot],
+                radius_sphere=params.radius_sphere, constraints=params.constraints[i_robot], nr_goals=len(goal.sub_goals()))
+        r.symbolic_forward_fabrics(planner, goal)
+        r.preset_radii_obsts_dyn(params.r_dyns_obsts[i_robot])
+        return r
 
     def preset_radii_obsts_dyn(self, radii_obst_dyn):
         self.radius_obsts_dyn = radii_obst_dyn

@@ -5,6 +5,7 @@ the HIP kernels behind csrc/libmrf_hip.so.  There is no CPU path; constructing a
 library or without a GPU raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -30,6 +31,8 @@ class FabricHandle:
         if not torch.cuda.is_available():
             raise MrfError("no HIP device visible to torch; the fabric solve has no CPU fallback")
         self.cfg = cfg.copy()
+        if os.environ.get("MRF_ABI_ANY") == "1":        # A/B timing of an older build (abi.load_library)
+            self.cfg.abi_version = self.lib.mrf_abi_version()
         if device is None:
             device = torch.cuda.current_device()
         if not isinstance(device, int):
@@ -161,6 +164,23 @@ class FabricHandle:
             self._arg(obst_v, (M, 3, rows), "obst_v"), self._arg(obst_a, (M, 3, rows), "obst_a"),
             self._arg(obst_r, (M, rows), "obst_r"), self._arg(avg), self._arg(tq), self._arg(tqd),
             self._stream(stream))
+        self._check(rc)
+        return (avg, tq, tqd) if want_traj else avg
+
+    def rollout_cartesian_coupled(self, q0, qdot0, params, want_traj=False, stream=None):
+        """Cartesian Rollout Fabrics of every robot against the other robots' configured spheres moving at constant
+        velocity, obstacle assembly on the device (EXC:330-399); rows = n_scenarios * n_robots -> avg_vel [rows]."""
+        rows = q0.shape[1]
+        N, H = self.cfg.n_robots, self.cfg.horizon
+        if rows % N:
+            raise MrfError("rows must be a multiple of n_robots")
+        avg = torch.empty((rows,), dtype=self.dtype, device=self.device)
+        tq = torch.empty((H, self.dof, rows), dtype=self.dtype, device=self.device) if want_traj else None
+        tqd = torch.empty_like(tq) if want_traj else None
+        rc = self.lib.mrf_rollout_cartesian_coupled(self._h, rows // N, self._arg(q0, (self.dof, rows), "q0"),
+                                                    self._arg(qdot0, (self.dof, rows), "qdot0"),
+                                                    self._arg(params, (abi.NPARAM, rows), "params"), self._arg(avg),
+                                                    self._arg(tq), self._arg(tqd), self._stream(stream))
         self._check(rc)
         return (avg, tq, tqd) if want_traj else avg
 
@@ -334,6 +354,16 @@ class FabricHandle:
         blob = b"".join(handles)
         self._check(self.lib.mrf_comm_peer_connect(self._h, (C.c_ubyte * len(blob)).from_buffer_copy(blob)))
 
+    def comm_info(self):
+        """What the communicator itself reports (mrf_comm_info): transport, rank, world, robot block, and -- RCCL -- the
+        rank count / user rank / device ncclCommCount, ncclCommUserRank and ncclCommCuDevice return."""
+        vals = (C.c_int32 * len(abi.COMM_INFO_KEYS))()
+        if self.lib.mrf_comm_info(self._h, vals, len(abi.COMM_INFO_KEYS)) != 0:
+            raise MrfError("mrf_comm_info failed")
+        out = dict(zip(abi.COMM_INFO_KEYS, (int(v) for v in vals)))
+        out["transport"] = {abi.TRANSPORT_NONE: "none", abi.TRANSPORT_RCCL: "rccl", abi.TRANSPORT_PEER: "peer"}[out["transport"]]
+        return out
+
     def comm_partition(self):
         first, count = C.c_int32(), C.c_int32()
         if self.lib.mrf_comm_partition(self._h, C.byref(first), C.byref(count)) != 0:
@@ -462,11 +492,14 @@ class ControlLoop:
     monitor only.  State (q, qdot, deadlock state) lives in this object's device tensors and is advanced in place."""
 
     def __init__(self, h_action, h_rollout, q, qdot, params, vel_limit, deadlock=True, apply_estimate=True,
-                 stop_margin=1e-3, sm_state=None, use_graph=True, pick_place=None):
+                 stop_margin=1e-3, sm_state=None, use_graph=True, pick_place=None, cartesian_rollouts=False):
         """pick_place: dict(start_goal [3,rows], blocks [nb,3,rows] (already lifted by 0.1, EXJ:303), nr_blocks,
         q_gripper [2,rows], model=1, h_grasp=None) -- runs the pick-and-place state machine on the device every step
         (mrf_episode_set_pick_place); its state is then in self.sm_state / self.sm_goal / self.q_gripper."""
         self.ha, self.hr = h_action, h_rollout
+        # cartesian_rollouts: the rollouts are the per-robot constant-velocity ones of example_pandas_cartesian.py
+        # (mrf_rollout_cartesian_coupled) instead of the coupled joint-space rollout
+        self.rollout_kind = abi.ROLLOUT_CARTESIAN if cartesian_rollouts else abi.ROLLOUT_JOINTSPACE
         if h_rollout is not None and (h_rollout.dtype != h_action.dtype or h_rollout.device != h_action.device or
                                       h_rollout.cfg.n_robots != h_action.cfg.n_robots):
             raise MrfError("rollout and action handles must agree in scalar type, device and n_robots")
@@ -529,6 +562,8 @@ class ControlLoop:
                 self.h_grasp._h if self.h_grasp is not None else None, p(self.action_grasp)))
         else:
             ha._check(ha.lib.mrf_episode_set_pick_place(ha._h, None, None, None, 0, None, None, None, None, None, None))
+        if hr is not None:
+            hr._check(hr.lib.mrf_episode_set_rollout(hr._h, self.rollout_kind))
         rc = ha.lib.mrf_episode_run(hr._h if hr is not None else None, ha._h, self.n_scen, int(n_steps),
                                     C.byref(self.dl_cfg) if self.dl_cfg is not None else None, int(self.apply_estimate),
                                     self.vel_limit, self.stop_margin, p(self.q), p(self.qdot), p(self.params),

@@ -74,6 +74,22 @@ def robot_partition(n_robots, G):
     return out
 
 
+def agree_on_error(err, world):
+    """Every rank of the job passes its error text (or None) and gets the first one any rank reported: either all ranks
+    raise or none does, so that no rank is left alone in a later world-wide collective."""
+    if world <= 1 or not dist.is_initialized():
+        return err
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    return next((f"rank {r}: {e}" for r, e in enumerate(errs) if e), None)
+
+
+def device_identity(device_index):
+    """Name and UUID of the GPU a rank runs on (for logs that must show N ranks sat on N different devices)."""
+    props = torch.cuda.get_device_properties(device_index)
+    return {"name": props.name, "uuid": str(getattr(props, "uuid", "")), "index": int(device_index)}
+
+
 class HipStepBackend:
     def __init__(self, cfg, device_index):
         from .runtime import FabricHandle
@@ -164,10 +180,9 @@ class ShardedRollout:
                         h.comm_peer_connect(handles)
                     except Exception as e:       # noqa: BLE001
                         err = str(e)
-            if self.G > 1:
-                errs = [None] * self.G
-                dist.all_gather_object(errs, err, group=self.group)
-                err = next((e for e in errs if e), None)
+            # agreed over the WORLD, not just the group: the callers go on with world-wide barriers and reductions, which
+            # a group that raised alone would leave the other groups waiting in
+            err = agree_on_error(err, world)
             if err:
                 raise RuntimeError(f"robot-group transport '{transport}' could not be set up: {err}")
             assert h.comm_partition() == (self.first, self.count)
@@ -227,18 +242,37 @@ class ShardedRollout:
         for _ in range(args.warmup):
             sr.rollout(q0.clone(), qd0.clone(), prm)
         barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(args.steps):
             avg = sr.rollout(q0.clone(), qd0.clone(), prm)
+        ev1.record()
         barrier()
         elapsed = time.perf_counter() - t0
+        own_ms = ev0.elapsed_time(ev1) / args.steps          # this rank's own device time per rollout, barrier not included
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        err = None
         if transport != "torch":
-            h.comm_status()          # a timed-out peer exchange raises here
-        assert torch.isfinite(avg).all()
+            try:
+                h.comm_status()          # a timed-out peer exchange is reported here
+            except Exception as e:       # noqa: BLE001
+                err = str(e)
+        if err is None and not bool(torch.isfinite(avg).all()):
+            err = "non-finite rollout result"
+        err = agree_on_error(err, world)
+        if err:
+            raise RuntimeError(f"robot-sharded rollout ({transport}): {err}")
+        # what every rank saw: its communicator (as RCCL itself reports it), its device, its own time per rollout
+        mine = {"rank": rank, "group": gi, "rollout_ms": own_ms, "device": device_identity(local_rank),
+                "comm": h.comm_info() if transport != "torch" else None}
+        ranks = [mine]
+        if world > 1:
+            ranks = [None] * world
+            dist.all_gather_object(ranks, mine)
         # parity of the sharded result with the fused single-GPU kernel on the first scenarios of the replica's batch
         from .runtime import FabricHandle
         nchk = min(B, 64)
@@ -268,6 +302,12 @@ class ShardedRollout:
             "rollout_steps_per_s": rate * N * H,
             "allgather_bytes_per_rank_per_step": sr.cnt_max * S * 9 * B * sb,
             "transport": transport,
+            "rccl_ranks_seen": sorted({r["comm"]["rccl_comm_count"] for r in ranks if r["comm"]}) if transport == "rccl" else None,
+            "rollout_ms_per_rank": {"min": min(r["rollout_ms"] for r in ranks), "max": max(r["rollout_ms"] for r in ranks),
+                                    "all": [round(r["rollout_ms"], 4) for r in ranks]},
+            "devices": [r["device"] for r in ranks],
+            "distinct_devices": len({(r["device"]["uuid"] or r["device"]["index"]) for r in ranks}),
+            "ranks": ranks,
             "parity_vs_fused_kernel": {"max_rel_err": perr, "tol": 1e-9 if cfg.scalar == abi.F64 else 2e-3,
                                        "ok": perr <= (1e-9 if cfg.scalar == abi.F64 else 2e-3), "scenarios": nchk},
             "roofline": ShardedRollout.roofline(cfg, sr, B, sb, elapsed / args.steps),

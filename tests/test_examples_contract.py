@@ -80,19 +80,23 @@ def test_shipped_urdf_is_the_compiled_chain():
             assert float(lim.get("lower")) == G["chain_lower"][i] and float(lim.get("upper")) == G["chain_upper"][i]
 
 
-def test_scene_stand_in_layout():
-    """create_manipulators_simulation without a GPU: the fixed scene's cubes (SIM:37-60,113-137) and the random scene's
-    validity rule (SIM:62-76)."""
+def test_cube_layouts():
+    """cell.cube_layout without a GPU: the fixed places (two columns between the mounts, three cubes per robot for two
+    robots, two for three; SIM:37-60,113-137) and the random scene's spacing rule (SIM:62-76)."""
     import examples.parameters_manipulators as pm
-    from examples.simulation_environments.create_simulation_manipulators import create_manipulators_simulation
+    from multi_robot_fabrics_amd.cell import cube_layout
     for n in (2, 3):
-        sim = create_manipulators_simulation(pm.manipulator_parameters(nr_robots=n))
-        cubes = sim.create_scene(random_scene=False, n_cubes=6)
-        assert len(cubes) == 6
-        pos = np.array([c._config.geometry.position for c in cubes])
-        assert np.allclose(pos[:, 2], 0.65 + 0.07) and set(np.round(pos[:, 0], 3)) == {0.4, 0.6}
-        assert np.allclose(sorted(set(np.round(pos[:, 1] - (0.2 if n == 3 else 0.0), 3))), [-0.15, 0.0, 0.15])
-        rnd = sim.create_scene(random_scene=True, n_cubes=6)
-        P = np.array([c._config.geometry.position for c in rnd])
-        d = np.linalg.norm(P[:, None] - P[None], axis=2) + 10 * np.identity(6)
-        assert d.min() > 0.05 + 0.06 and P[:, 0].min() >= 0.4 and P[:, 0].max() <= 0.6
+        p = pm.manipulator_parameters(nr_robots=n)
+        fixed = cube_layout(p)
+        assert fixed.shape == (1, 6, 3)
+        assert np.allclose(fixed[0, :, 2], 0.65 + 0.025) and set(np.round(fixed[0, :, 0], 3)) == {0.4, 0.6}
+        assert np.allclose(sorted(set(np.round(fixed[0, :, 1] - (0.2 if n == 3 else 0.0), 3))), [-0.15, 0.0, 0.15])
+        assert len({tuple(np.round(c, 6)) for c in fixed[0]}) == 6
+        rnd = cube_layout(p, random_scene=True, rng=np.random.default_rng(5), scenes=3)
+        assert rnd.shape == (3, 6, 3)
+        for P in rnd:
+            d = np.linalg.norm(P[:, None, :2] - P[None, :, :2], axis=2) + 10 * np.identity(6)
+            assert d.min() > 0.05 + 0.06 and P[:, 0].min() >= 0.4 and P[:, 0].max() <= 0.6
+        assert not np.allclose(rnd[0], rnd[1])
+    two = cube_layout(pm.manipulator_parameters(nr_robots=2), n_cubes=2)[0]
+    assert np.allclose(two[:, :2], [[0.4, 0.0], [0.6, -0.15]])      # one cube each: the first place of either column

@@ -1,7 +1,7 @@
 """The example and evaluation drivers end to end on the GPU, called exactly as the reference's own smoke test calls
 them (examples/test_examples.py:8-36: `test_main(n_steps=100, render=False)` must return a dict) -- plus what that test
-does not ask for: the reference's result keys, the pick-and-place cycle actually completing, the host-API loop against the
-same configuration as a device-resident episode, and the two evaluation protocols."""
+does not ask for: the reference's result keys, the pick-and-place cycle actually completing, the driver against a
+hand-built device-resident episode of the same cell, and the two evaluation protocols."""
 import os
 import pickle
 import warnings
@@ -52,6 +52,13 @@ def test_example_pandas_cartesian():
     res = blueprint_test(define_run_panda_example)
     assert KEYS <= set(res)
     assert res["solver_times"].shape == (100,) and np.isfinite(res["solver_times"]).all()
+    assert res["config"]["n_obst_per_link"] == 4                    # 32 constant-velocity obstacle spheres per robot
+
+
+def test_panda_examples_default_render_warns():
+    from examples.example_pandas_cartesian import define_run_panda_example
+    with pytest.warns(RuntimeWarning, match="no renderer"):
+        assert isinstance(define_run_panda_example(n_steps=2), dict)            # the reference's default render=True
 
 
 def test_render_true_is_ignored_with_a_warning():
@@ -81,37 +88,80 @@ def _yaml(tmp_path, **over):
     return str(path)
 
 
-def test_jointspace_host_loop_matches_device_resident_episode(tmp_path):
-    """The same configuration stepped through the mirrored host classes (one launch per reference call) and as ONE
-    device-resident episode (mrf_episode_run with the state machine and the grasp planner on the device): same states,
-    same motion.  n_obst_per_link = 1 so that the host loop's link-origin velocities (EXJ:409-410) are the spheres'."""
+def test_jointspace_example_is_the_device_resident_episode(tmp_path):
+    """The driver's result is what runtime.ControlLoop produces for the same cell built by hand from config.* (the
+    per-stage parity of that loop against the oracle and against a host-stepped loop is tests/test_gpu_control.py and
+    tests/test_gpu_pick_place.py): same joint state after 350 control steps, to the last bit."""
+    import torch
     from examples.example_pandas_Jointspace import define_run_panda_example
-    res = define_run_panda_example(n_steps=350, render=False, config_path=_yaml(tmp_path), device_episode=True)
-    assert res["control_steps"] == 350
-    assert res["host_api_vs_device_episode_max_abs_dq"] < 1e-6, res["host_api_vs_device_episode_max_abs_dq"]
-    assert res["device_resident_ms_per_control_step"] < 5.0
+    from multi_robot_fabrics_amd import abi, config
+    from multi_robot_fabrics_amd.cell import cube_layout, nominal_parameters
+    from multi_robot_fabrics_amd.parameters import load_yaml_settings
+    from multi_robot_fabrics_amd.runtime import ControlLoop, FabricHandle
+    path = _yaml(tmp_path)
+    res = define_run_panda_example(n_steps=350, render=False, config_path=path)
+    assert res["control_steps"] == 350 and res["solver_times"].shape == (350,)
+    assert 0 < np.median(res["solver_times"]) < 5e-3                       # device time of one control step [s]
+    p, _ = load_yaml_settings(path)
+    ca = config.panda_config(n_robots=2, horizon=1, dynamic=0, mounts=p.mount_transform)   # main planners: static (see the driver)
+    links, offsets = config.sphere_offsets_per_link(p.n_obst_per_link)                      # the simulator's sphere per link
+    config.set_spheres(ca, links, offsets, [p.radius_sphere] * len(links))
+    cg = config.panda_config(n_robots=2, horizon=1, dynamic=0, n_ego=0, mounts=p.mount_transform)
+    cr = config.panda_config(n_robots=2, horizon=10, dynamic=1, mounts=p.mount_transform)
+    ha, hg, hr = FabricHandle(ca), FabricHandle(cg), FabricHandle(cr)
+    cubes = cube_layout(p)[0]
+    blocks = np.zeros((3, 3, 2))
+    for i in range(2):
+        for b in range(3):
+            blocks[b, :, i] = cubes[3 * i + b] + [0, 0, 0.1]
+    q0 = np.array([np.asarray(x, dtype=float)[:7] for x in p.pos0]).T
+    t = ha.tensor
+    loop = ControlLoop(ha, hr, t(q0), t(np.zeros_like(q0)), t(nominal_parameters(p)), config.PANDA_VEL_LIMITS, deadlock=True,
+                       apply_estimate=False, stop_margin=-1.0,
+                       pick_place=dict(start_goal=t(np.array(p.start_goals, dtype=float).T), blocks=t(blocks), nr_blocks=3,
+                                       q_gripper=t(np.full((2, 2), 0.02)), model=1, h_grasp=hg))
+    loop.run(350)
+    torch.cuda.synchronize()
+    assert np.array_equal(loop.q.cpu().numpy().T, res["q_final"])
+    assert res["states"] == [int(v) for v in loop.sm_state[abi.SM_STATE].cpu().numpy()]
 
 
 def test_jointspace_three_robots_without_rollouts(tmp_path):
     from examples.example_pandas_Jointspace import define_run_panda_example
-    res = define_run_panda_example(n_steps=25, render=False, device_episode=True,
+    res = define_run_panda_example(n_steps=25, render=False,
                                    config_path=_yaml(tmp_path, n_robots=3, ROLLOUT_FABRICS=False, STATIC_OR_DYN_FABRICS=0,
                                                      RESOLVE_DEADLOCKS=0, N_HORIZON=5))
     assert res["config"]["n_robots"] == 3 and res["time_in_deadlock_steps"] == 0 and KEYS <= set(res)
-    assert res["host_api_vs_device_episode_max_abs_dq"] < 1e-9
+    assert res["control_steps"] == 25 and np.isfinite(res["q_final"]).all() and res["q_final"].shape == (3, 7)
+
+
+def test_jointspace_example_many_scenes(tmp_path):
+    """`scenes` copies of the cell advance in the same launches."""
+    from examples.example_pandas_Jointspace import define_run_panda_example
+    one = define_run_panda_example(n_steps=60, render=False, config_path=_yaml(tmp_path))
+    many = define_run_panda_example(n_steps=60, render=False, config_path=_yaml(tmp_path), scenes=5)
+    assert np.allclose(one["q_final"], many["q_final"], rtol=0, atol=1e-12)         # scene 0 of five == the single scene
+    assert len(many["all_scenes"]["min_clearance_m"]) == 5
 
 
 def test_cartesian_example_completes_pick_and_place(tmp_path):
-    """EXC:194-524 through the mirrored classes -- per-robot FabricsRollouts, compute_x_obsts_dyn_0, deadlock_checking,
-    main / grasp planner by state, the host state machine -- one cube per robot, until both robots report state 10."""
+    """Per-robot Cartesian Rollout Fabrics on the device (mrf_rollout_cartesian_coupled), deadlock logic, main / grasp
+    planner by state, one cube per robot, until both robots report state 10."""
     from examples.example_pandas_cartesian import define_run_panda_example
-    res = define_run_panda_example(n_steps=3000, render=False, config_path=_yaml(tmp_path, N_HORIZON=5),
-                                   overrides={"n_cubes": 2})
+    res = define_run_panda_example(n_steps=3000, render=False, config_path=_yaml(tmp_path, N_HORIZON=5), n_cubes=2)
     assert res["blocks_picked"] == [1, 1] and res["success_rate"] == 1
     assert res["n_steps_panda"] < 3000 and res["n_steps_robot2"] < 3000
     assert res["total_time"] == max(res["n_steps_panda"], res["n_steps_robot2"]) * 0.01
-    assert all({1, 2, 3, 12, 4, 5, 10} <= set(s) for s in res["states_visited"])
+    assert res["control_steps"] == max(res["n_steps_panda"], res["n_steps_robot2"])
+    assert all({1, 2, 3, 12, 4, 5} <= set(s) for s in res["states_visited"])
     assert res["min clearance"] > 0.0
+
+
+def test_jointspace_example_completes_pick_and_place(tmp_path):
+    from examples.example_pandas_Jointspace import define_run_panda_example
+    res = define_run_panda_example(n_steps=9000, render=False, config_path=_yaml(tmp_path, N_HORIZON=5))
+    assert res["blocks_picked"] == [3, 3] and res["success_rate"] == 1 and res["min clearance"] > 0.0
+    assert res["control_steps"] == max(res["n_steps_panda"], res["n_steps_robot2"]) < 9000
 
 
 def test_evaluate_horizon_protocol(tmp_path):

@@ -221,6 +221,32 @@ def test_rollout_cartesian_more_obstacles_than_resident(oracle, accel):
     assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
 
 
+@pytest.mark.parametrize("n_robots,per_link,dynamic", [(2, 1, 1), (3, 2, 1), (2, 4, 1), (3, 1, 0), (1, 1, 1)])
+def test_rollout_cartesian_coupled(oracle, n_robots, per_link, dynamic):
+    """mrf_rollout_cartesian_coupled (EXC:330-399 on the device): every robot's Cartesian rollout against the configured
+    spheres of the other robots of its scenario -- the simulator's table with per_link spheres per link, positions and
+    velocities at the start state, zero accelerations -- equals the oracle's rollout_cartesian fed with the host-side
+    assembly of those obstacles (static fabrics: zero obstacle velocities; one robot: no obstacles)."""
+    cfg = config.panda_config(n_robots=n_robots, horizon=5, dynamic=dynamic)
+    links, offs = config.sphere_offsets_per_link(per_link)
+    config.set_spheres(cfg, links, offs, [0.07 + 0.001 * (s % 5) for s in range(len(links))])
+    batch = scenarios.panda_batch(cfg, 23, seed=43, x_min=0.1)
+    sx, sv, _ = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv if dynamic else None, None)
+    assert ox.shape[0] == 8 * per_link * (n_robots - 1)
+    want_avg, want_q, want_qd = oracle.rollout_cartesian(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad, traj=True)
+    h = FabricHandle(cfg, 0)
+    t = h.tensor
+    avg, tq, tqd = h.rollout_cartesian_coupled(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL and relerr(tq.cpu().numpy(), want_q) < F64_RTOL
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+    # a larger batch afterwards grows the handle's obstacle work buffer; results of the first rows do not change
+    big = scenarios.panda_batch(cfg, 200, seed=43, x_min=0.1)
+    avg2 = h.rollout_cartesian_coupled(t(big["q"]), t(big["qdot"]), t(big["params"]))
+    assert avg2.shape == (200 * n_robots,) and torch.isfinite(avg2).all()
+    assert torch.equal(h.rollout_cartesian_coupled(t(batch["q"]), t(batch["qdot"]), t(batch["params"])), avg)
+
+
 def test_fk_spheres_with_offsets(oracle):
     cfg = config.panda_config(n_robots=3, horizon=1)
     links, offs = config.sphere_offsets_per_link(4)
