@@ -10,6 +10,10 @@ data path); `rollout_steps_per_s` = robot x horizon-step fabric evaluations per 
 the north-star partitioning is timed instead: one robot (or a contiguous group) per GPU with an RCCL all-gather
 of predicted collision-sphere states after every rollout step.
 
+Beside the headline the `--gpus 1` line carries: `configs` (the other BASELINE.json configurations C2 / C3 / C5 and the
+Cartesian rollout, each event-timed with its own roofline entry and a 64-scenario oracle spot check), `clock` (the
+shader clock the timed rollout kernel ran at, measured inside the kernel) and `roofline.frac_at_measured_clock`.
+
 Prints ONE JSON line on rank 0.  Run:  python bench.py [--gpus N --steps K --warmup W]
 N>1 works both ways: under an external launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N
 --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...), or bare -- then this process starts that launcher as a
@@ -26,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np
+
+
+SHARD_TIMEOUT_RC = 3   # a hung exchange in a process that has touched the GPU must not look like a clean run
 
 
 def spawn_ranks(argv, n):
@@ -48,6 +55,15 @@ def spawn_ranks(argv, n):
         else:
             sys.stderr.write(line)
     rc = proc.wait()
+    # exit code SHARD_TIMEOUT_RC from the ranks = "the headline line is complete, the secondary robot-sharded block timed out
+    # and the ranks left without tearing the process group down": the line is relayed and the code passed on
+    if rc != 0 and len(json_lines) == 1:
+        try:
+            rs = json.loads(json_lines[0]).get("robot_sharded", {})
+            if "error" in rs or any(isinstance(v, dict) and "error" in v for v in rs.values()):
+                rc = SHARD_TIMEOUT_RC
+        except ValueError:
+            pass
     if rc == 0 and len(json_lines) != 1:
         sys.stderr.write(f"expected one JSON line from rank 0, got {len(json_lines)}\n")
         rc = 1
@@ -65,6 +81,7 @@ if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
 
 import torch
 
+NOMINAL_SHADER_GHZ = 2.4         # the clock the guide's peaks are quoted at (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz = 78.6 TF f64)
 F64_VECTOR_PEAK = 157.3e12 / 2   # FLOP/s: MI355X_MICROARCH.md "Peak FP32 (vector)" / 2 (f64 issues at half the f32 rate)
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6.29e12 measured copy
 
@@ -188,6 +205,110 @@ def parity_spot_check(cfg_roll, cfg_act, batch, avg, act, n_scen=64, tol=1e-9):
             "against": "oracle/mrf_oracle.cpp (float64 CPU restatement) on the first scenarios of the timed batch"}
 
 
+def _traffic_entry(prefix):
+    """(exact-or-latest entry of profiles/traffic.json whose key starts with `prefix`, its key)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as f:
+        tj = json.load(f)
+    keys = [k for k in sorted(tj) if k.startswith(prefix) and isinstance(tj[k], dict)]
+    return (tj[keys[-1]], keys[-1]) if keys else (None, None)
+
+
+def config_sizes(name, cus):
+    """Scenarios per launch of a `configs` entry: C2 as SURVEY 8d names it, the others two full rounds of resident waves."""
+    n = {"C2": 2, "C3": 2, "C5": 8, "CART": 3}[name]
+    return 65536 if name == "C2" else 2 * cus * 4 * (64 // n)
+
+
+def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
+    """One BASELINE configuration beside the headline: kernel time by HIP events, rates, a roofline entry from the stamped
+    counter file (profiles/traffic.json key config_<name>_<dtype>_B<B>) and an oracle spot check on 64 scenarios."""
+    from multi_robot_fabrics_amd import abi, scenarios
+    from multi_robot_fabrics_amd.runtime import FabricHandle
+    scalar = abi.F64 if dtype == "f64" else abi.F32
+    sb = 8 if dtype == "f64" else 4
+    spec = scenarios.baseline_config(name, scalar)
+    cfg, kind = spec["cfg"], spec["kind"]
+    N, H, S = cfg.n_robots, cfg.horizon, cfg.n_spheres
+    cus = torch.cuda.get_device_properties(device_index).multi_processor_count
+    B = config_sizes(name, cus)
+    batch = scenarios.tiled_batch(cfg, B, seed=77, **spec["batch"])
+    h = FabricHandle(cfg, device_index)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    rows = B * N
+    M = S * (N - 1)
+    if kind == "action_coupled":
+        launch = lambda: h.compute_action_coupled(q, qd, prm, use_accel=False)
+        units, unit_name, kernel = rows, "control-steps of one robot", "k_action_coupled"
+        bytes_unit = sb * (14 + 23 + 10 * M + 7)                                  # SURVEY 8d, control step without rollout
+    elif kind == "rollout":
+        launch = lambda: h.rollout(q, qd, prm)
+        units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_panda"
+        bytes_unit = algorithmic_bytes_per_rollout_step(N, S, H, sb)
+    else:
+        sx, sv, _ = h.fk_spheres(q, qd)
+        ox, ov, _, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, None)
+        launch = lambda: h.rollout_cartesian(q, qd, prm, ox, ov, None, orad)
+        units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_cart_panda"
+        bytes_unit = sb * (28 + 7 * M) + sb * 23 / H                              # state in/out + the M obstacles re-read per step
+    for _ in range(warmup):
+        out = launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    res = {"workload": spec["label"], "kernel": kernel, "scenarios": B, "robots": N, "horizon": H, "spheres_per_robot": S,
+           "kernel_ms": ms, "launches_timed": iters, "unit": unit_name, "units_per_s": units / (ms * 1e-3),
+           "scenarios_per_s": B / (ms * 1e-3), "dtype": dtype}
+    peak_tf = (F64_VECTOR_PEAK if dtype == "f64" else 2 * F64_VECTOR_PEAK) / 1e12
+    alg = units * bytes_unit / (ms * 1e-3)
+    roof = {"hbm_algorithmic": {"achieved": alg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / HBM_PEAK,
+                                "bytes_per_unit": bytes_unit}}
+    src, key = _traffic_entry(f"config_{name}_{dtype}_")
+    if src is not None and "flops_per_unit" in src:
+        tf = units * src["flops_per_unit"] / (ms * 1e-3) / 1e12
+        roof.update(bound="valu_" + dtype, achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf,
+                    flops_per_unit=src["flops_per_unit"], traffic_key=key,
+                    traffic=(src["bytes_per_launch"] / (ms * 1e-3) / 1e9) if key.endswith(f"_B{B}") else None, traffic_unit="GB/s")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from make_traffic import kernel_source_sha256
+        roof["roofline_inputs_stale"] = src.get("kernel_source_sha256") != kernel_source_sha256()
+    else:
+        roof.update(bound="hbm", achieved=alg / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=alg / HBM_PEAK, traffic=None,
+                    note="no counter pass recorded for this configuration: formulation-equivalent bytes only")
+    res["roofline"] = roof
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        n = 64
+        sel = slice(0, n * N)
+        bq, bqd, bp = batch["q"][:, sel], batch["qdot"][:, sel], batch["params"][:, sel]
+        oracle_lib.set_threads(min(8, os.cpu_count() or 1))
+        if kind == "action_coupled":
+            sx, sv, _ = oracle_lib.fk_spheres(cfg, bq, bqd)
+            o = scenarios.other_robot_obstacles(cfg, None, sx, sv, None)
+            _, want = oracle_lib.compute_action(cfg, bq, bqd, bp, *o)
+            got = out[:, sel].double().cpu().numpy()
+        elif kind == "rollout":
+            want, _, _ = oracle_lib.rollout(cfg, bq, bqd, bp)
+            got = out[sel].double().cpu().numpy()
+        else:
+            sx, sv, _ = oracle_lib.fk_spheres(cfg, bq, bqd)
+            o = scenarios.other_robot_obstacles(cfg, None, sx, sv, None)
+            want, _, _ = oracle_lib.rollout_cartesian(cfg, bq, bqd, bp, *o)
+            got = out[sel].double().cpu().numpy()
+        err = float(np.abs(got - want).max() / max(1e-300, np.abs(want).max()))
+        tol = 1e-9 if dtype == "f64" else 2e-3
+        res["parity_spot_check"] = {"max_rel_err": err, "tol": tol, "ok": bool(err <= tol), "scenarios": n}
+    return res
+
+
 def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     """Secondary block of the default run: the north-star partitioning (robots of a scenario spread over the GPUs of a
     group, per-step exchange of predicted sphere states) on the same batch, rollout only, for both
@@ -210,7 +331,9 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
         try:
             r = ShardedRollout.bench(cfg_roll, batch, a, rank, world, local_rank)
             out[transport] = {k: r[k] for k in ("value", "unit", "ms_per_step", "rollout_steps_per_s", "steps",
-                                                "allgather_bytes_per_rank_per_step", "parity_vs_fused_kernel", "roofline")}
+                                                "allgather_bytes_per_rank_per_step", "parity_vs_fused_kernel", "roofline",
+                                                "rccl_ranks_seen", "rollout_ms_per_rank", "devices", "distinct_devices",
+                                                "ranks")}
             out[transport]["config"] = r["config"]
         except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
             out[transport] = {"error": f"{type(e).__name__}: {e}"[:400]}
@@ -272,6 +395,7 @@ def main():
                     help="--shard robots: exchange inside the library over RCCL (default) or peer-mapped buffers, or the Python loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-robot-shard", action="store_true", help="skip the secondary robot-sharded block of the default run")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (C2, C3, C5, Cartesian rollout) of the --gpus 1 line")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: libraries print banners there (RCCL's version block on communicator
@@ -363,7 +487,14 @@ def main():
         avg, act = control_step(k)
     barrier()
     elapsed = time.perf_counter() - t0
+    own_gpu_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # this rank's rollout kernel, from its own events
+    from multi_robot_fabrics_amd.sharded import device_identity
+    mine = {"rank": rank, "elapsed_s": elapsed, "rollout_kernel_ms": own_gpu_ms, "device": device_identity(local_rank),
+            "clock": h_roll.rollout_clock()}
+    per_rank = [mine]
     if world > 1:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -408,6 +539,12 @@ def main():
             roofline = dict(hbm_alg, traffic=traffic, traffic_source=traffic_src)
         roofline.update({"kernel": "k_rollout_panda", "units_per_launch": units, "kernel_ms": roll_ms,
                          "hbm_algorithmic": hbm_alg})
+        # the clock the timed kernel ran at (stamped by its first and last workgroup): the peak above is quoted at
+        # NOMINAL_SHADER_GHZ, so the fraction of what THIS device could do at THIS clock is frac * nominal / measured
+        clock = mine["clock"]
+        ghz = clock.get("shader_ghz")
+        roofline["effective_clock_ghz"] = ghz
+        roofline["frac_at_measured_clock"] = (roofline["frac"] * NOMINAL_SHADER_GHZ / ghz) if ghz else None
         # the counters behind flops_per_unit / traffic belong to one version of the kernel sources (stamped by
         # tools/make_traffic.py): say so when the sources in this tree are not that version
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -427,7 +564,20 @@ def main():
                        "sharding": "scenarios (independent, no collective)"},
             "rollout_steps_per_s": world * units * args.steps / elapsed,
             "rollout_kernel_ms": roll_ms,
+            "effective_clock_ghz": ghz,
+            "clock": dict(clock, nominal_ghz=NOMINAL_SHADER_GHZ,
+                          how="s_memtime / s_memrealtime deltas stamped inside the timed k_rollout_panda launches "
+                              "(include/mrf.h mrf_rollout_clock)"),
             "roofline": roofline,
+            # what the MAX over ranks was taken of (one entry at --gpus 1)
+            "per_rank": {"elapsed_s": {"min": min(r["elapsed_s"] for r in per_rank), "max": max(r["elapsed_s"] for r in per_rank),
+                                       "all": [round(r["elapsed_s"], 6) for r in per_rank]},
+                         "rollout_kernel_ms": {"min": min(r["rollout_kernel_ms"] for r in per_rank),
+                                               "max": max(r["rollout_kernel_ms"] for r in per_rank),
+                                               "all": [round(r["rollout_kernel_ms"], 4) for r in per_rank]},
+                         "shader_ghz": [r["clock"].get("shader_ghz") for r in per_rank],
+                         "devices": [r["device"] for r in per_rank],
+                         "distinct_devices": len({(r["device"]["uuid"] or r["device"]["index"]) for r in per_rank})},
         }
         out["parity_spot_check"] = parity_spot_check(cfg_roll, cfg_act, batch, avg, act)
 
@@ -442,7 +592,7 @@ def main():
             if rank == 0:
                 out["robot_sharded"] = {"error": f"timeout: the robot-sharded block did not finish within {guard_s:.0f} s"}
                 emit(out)
-            os._exit(0)
+            os._exit(SHARD_TIMEOUT_RC)     # every rank: the run is NOT clean (spawn_ranks / the tests know this code)
 
         guard_s = float(os.environ.get("MRF_BENCH_SHARD_TIMEOUT_S", "240"))
         sharded_block = run_guarded(lambda: robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank),
@@ -452,11 +602,19 @@ def main():
     if rank == 0:
         if world == 1:
             out["single_scenario"] = single_scenario_latency(h_roll, h_act, batch, N, S)
+        if world == 1 and not args.no_configs:
+            from multi_robot_fabrics_amd import scenarios as _sc
+            out["configs"] = {}
+            for name in _sc.BASELINE_CONFIGS:
+                try:
+                    out["configs"][name] = run_config(name, args.dtype, local_rank)
+                except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the headline with it
+                    out["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_roll, cfg_act, batch)
         emit(out)
     if world > 1:   # the line is out: a peer that already left (guard above) must not keep this rank in the teardown
-        run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: os._exit(0))
+        run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: os._exit(SHARD_TIMEOUT_RC))
 
 
 if __name__ == "__main__":

@@ -162,6 +162,14 @@ int mrf_rollout(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* 
  * trajectories traj_q / traj_qd [H][dof][rows] mrf_rollout has written -- positions after the step's position update,
  * v = J qdot and a = jdot_sign * Jdot qdot with the velocities that ENTER the step (qdot0 for step 0, traj_qd[k-1]
  * after).  x_out, v_out, a_out [H][S][3][rows] (v_out / a_out may be NULL); one mrf_fk_spheres launch per step. */
+/* The clock the LAST row-per-lane mrf_rollout of this handle ran at, measured inside the kernel: its first and its last
+ * workgroup stamp the shader-cycle counter (s_memtime) and the constant-rate wall clock (s_memrealtime) on entry and on
+ * exit.  Synchronises the device.  out[i], i < n <= MRF_ROLLOUT_CLOCK_N:
+ *   0, 1  shader clock [GHz] seen by the first / last workgroup (0: no rollout yet, or the cooperative kernel ran)
+ *   2, 3  lifetime of that workgroup [ms]      4  wall-clock rate [GHz]
+ * Two boxes (or two runs) whose kernel times differ can be told apart by it: same cycles at a lower clock, or more cycles. */
+#define MRF_ROLLOUT_CLOCK_N 5
+int mrf_rollout_clock(mrf_handle* h, double* out, int32_t n);
 int mrf_rollout_sphere_traj(mrf_handle* h, int64_t n_scenarios, const void* qdot0, const void* traj_q, const void* traj_qd,
                             void* x_out, void* v_out, void* a_out, void* stream);
 

@@ -1062,8 +1062,13 @@ __host__ __device__ __forceinline__ int lo_count(int slot, int m01, int m45) {
 // The link-origin kernels keep the own chain's kinematics alive across the sphere loop (single walk) only with the
 // compile-time leaf policies; the runtime-family leaves need the registers, there the chain is re-walked instead
 // (the single-walk form spilled 544 B of scratch per lane in the generic instantiation).
+#ifdef MRF_PAIR_TWO_WALKS  // experiment: the pair-symmetric loop with the chain re-walked after it (frees ~190 registers)
+template <class LS>
+constexpr bool kSingleWalk = false;
+#else
 template <class LS>
 constexpr bool kSingleWalk = !LS::Collision::generic;
+#endif
 
 
 // ------------------------------------------------------------------------------------ planar point robot

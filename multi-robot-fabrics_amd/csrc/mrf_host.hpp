@@ -37,6 +37,7 @@ struct mrf_handle {
   } pp;
   // mrf_rollout_cartesian_coupled (mrf_control.hip): obstacle arrays assembled on the device, grown on demand (never
   // inside a stream capture: mrf_episode_run sizes them before it captures)
+  void* clock_probe = nullptr;  // 8 x int64 written by the first / last workgroup of k_rollout_panda (mrf_rollout_clock)
   void* cart_work = nullptr;
   size_t cart_work_bytes = 0;
   int episode_rollout_kind = 0;  // mrf_episode_set_rollout: which rollout an episode on this ROLLOUT handle runs

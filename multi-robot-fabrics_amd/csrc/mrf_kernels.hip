@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -186,9 +187,9 @@ __device__ __forceinline__ void obstacles_resident(const DevCfg<T>& cfg, const T
 // One pipelined loop over ALL obstacles of a row: the first nres come from the resident LDS tile, the rest from the HBM
 // arrays (wave-uniform switch inside the fetch).  A single loop keeps one pair of ping-pong buffers and two inlined copies
 // of the five-point fold alive instead of two loops with four.  Streamed loads use RowAddr (uniform base + lane offset).
-template <class CL, bool ACC, typename T>
+template <class CL, bool ACC, typename T, class ADDR>
 __device__ __forceinline__ void obstacles_cart(const DevCfg<T>& cfg, const T* __restrict__ res, int lane, int nres,
-                                               const RowAddr<T>& ra, int n_obst, int n_static,
+                                               const ADDR& ra, int n_obst, int n_static,
                                                const T* __restrict__ ox, const T* __restrict__ ov,
                                                const T* __restrict__ oa, const T* __restrict__ orad, T tk,
                                                const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
@@ -422,6 +423,10 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
   if (m < M) accumulate_obstacle<CL>(cfg, E, bufA, bufA + 3, bufA + 6, bufA[9], false, acc, bufA[10]);  // odd count
 }
 
+#ifdef MRF_PAIR_SYMMETRY  // experiment build (profiles/r04_experiments.json): measured slower, not part of the shipped kernels
+#include "experiments/pair_symmetry.hpp"
+#endif
+
 // Generic sphere tables (offset spheres, any count): every lane walks ITS OWN chain once, emitting its spheres in
 // table order; they are exchanged CH at a time through a [CH][9][64] LDS tile (18 KB in f64) and each lane folds the
 // chunk's spheres of the other robots of its scenario before the walk moves on -- instead of every lane re-walking all
@@ -486,9 +491,18 @@ template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
-                                                       T* __restrict__ traj_q, T* __restrict__ traj_qd) {
+                                                       T* __restrict__ traj_q, T* __restrict__ traj_qd,
+                                                       long long* __restrict__ probe) {
   __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
   const DevCfg<T>& cfg = *cfgp;
+  // clock probe (mrf_rollout_clock): the first and the last workgroup stamp the shader-cycle counter (s_memtime) and the
+  // constant-rate wall clock on entry and on exit -- stored at once, nothing is carried through the step loop
+  const bool probing = probe && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 0;
+  long long* const stamp = probe + (blockIdx.x == 0 ? 0 : 4);
+  if (probing) {
+    stamp[0] = (long long)__builtin_readcyclecounter();
+    stamp[1] = (long long)wall_clock64();
+  }
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
   const int spw = 64 / N;  // scenarios per wave
@@ -550,6 +564,12 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
       panda_solve_row<LS, kSingleWalk<LS>>(
           cfg, mount_own, R, P,
           [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+#ifdef MRF_PAIR_SYMMETRY  // experiment build: odd N >= 3, both coincident pairs merged (not checked here)
+            if constexpr (!LS::Collision::generic) {
+              obstacles_from_tile_paired<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
+              return;
+            }
+#endif
             obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
           },
           qdd, act,
@@ -589,6 +609,10 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
     }
   }
   if (active) avg_out[row] = sumsq / (T)(H * 7);  // FPJ:102-116
+  if (probing) {
+    stamp[2] = (long long)__builtin_readcyclecounter();
+    stamp[3] = (long long)wall_clock64();
+  }
 }
 
 // ---------------------------------------------------------------------------- coupled compute_action
@@ -958,31 +982,35 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
   const DevCfg<T>& cfg = *cfgp;
   PandaState<T> R;
   load_state(rows, r, q0, qd0, R);
-  PrmViewU<T> P{prm, ra, {T(0), T(0), T(0)}, false};
+  // measured (profiles/r04_experiments.json, H=30, M=16, f64): the uniform-base addressing pays without obstacle
+  // accelerations (3.81 -> 3.72 ms, scratch 44 -> 20 B per lane); with them the allocator trades it for more scratch
+  // (60 -> 84 B, 4.05 -> 4.19 ms), so that instantiation keeps the per-lane addresses
+  using Addr = std::conditional_t<ACC, LaneAddr<T>, RowAddr<T>>;
+  using Prm = std::conditional_t<ACC, PrmView<T>, PrmViewU<T>>;
+  Addr addr;
+  Prm P;
+  if constexpr (ACC) {
+    addr = LaneAddr<T>{rows, r};
+    P = PrmView<T>{prm, rows, r, {T(0), T(0), T(0)}, false};
+  } else {
+    addr = ra;
+    P = PrmViewU<T>{prm, ra, {T(0), T(0), T(0)}, false};
+  }
   const int li = (int)(r % cfg.n_robots);
-#ifdef MRF_CART_MOUNT_LDS
-  // experiment (profiles/r04_experiments.json): the mount transform is a per-lane loop invariant (12 values, and with it
-  // joint 1's axis and origin); staged in LDS once and re-read in every step through an index the optimizer cannot hoist
-  __shared__ T mnt[MRF_MAX_ROBOTS * 12];
-  for (int w = threadIdx.x; w < cfg.n_robots * 12; w += blockDim.x) mnt[w] = cfg.mount[w / 12][w % 12];
-#else
   const T* mount_own = cfg.mount[li];
-#endif
   constexpr int NRES = CART_RESIDENT<T, ACC>;
   __shared__ T res[RES ? NRES * (ACC ? 10 : 7) * 64 : 1];
   const int nres = RES ? (n_obst < NRES ? n_obst : NRES) : 0;
   if constexpr (RES) stage_resident_obstacles<ACC>(res, (int)threadIdx.x, nres, rows, r, ox0, ov, oa, orad);
   __syncthreads();
   T sumsq = T(0);
+  T tk_lane = T(0);
   const int H = cfg.horizon;
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
-    const T tk = to_uniform((T)k * cfg.dt);  // elapsed obstacle time (FPC:448-453: x += dt*v per step)
-#ifdef MRF_CART_MOUNT_LDS
-    int li_k = li;
-    asm volatile("" : "+v"(li_k));
-    const T* mount_own = mnt + li_k * 12;
-#endif
+    // elapsed obstacle time (FPC:448-453: x += dt*v per step): a scalar in the instantiation without accelerations, a
+    // per-lane running sum in the other one (measured: the scalar form costs that one 4.05 -> 4.3 ms)
+    const T tk = ACC ? tk_lane : to_uniform((T)k * cfg.dt);
     T qdd[7], act[7];
     panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
@@ -999,13 +1027,13 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
           if constexpr (RES && two_loops) {
             obstacles_resident<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, n_static, ov != nullptr,
                                                             oa != nullptr, tk, E, acc);
-            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, ra, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
+            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, addr, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
                                                                nres);
           } else if constexpr (RES) {
-            obstacles_cart<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, ra, n_obst, n_static, ox0, ov, oa,
+            obstacles_cart<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, addr, n_obst, n_static, ox0, ov, oa,
                                                         orad, tk, E, acc);
           } else {
-            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, ra, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
+            obstacles_from_arrays<typename LS::Collision, ACC>(cfg, addr, n_obst, n_static, ox0, ov, oa, orad, tk, false, E, acc,
                                                                0);
           }
         },
@@ -1042,14 +1070,25 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
     }
     if (active && traj_q) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) ra.store(traj_q, (int64_t)k * 7 + j, R.q[j]);
+      for (int j = 0; j < 7; ++j) {
+        if constexpr (ACC)
+          traj_q[((int64_t)k * 7 + j) * rows + r] = R.q[j];
+        else
+          ra.store(traj_q, (int64_t)k * 7 + j, R.q[j]);
+      }
     }
     if (active && traj_qd) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) ra.store(traj_qd, (int64_t)k * 7 + j, R.qd[j]);
+      for (int j = 0; j < 7; ++j) {
+        if constexpr (ACC)
+          traj_qd[((int64_t)k * 7 + j) * rows + r] = R.qd[j];
+        else
+          ra.store(traj_qd, (int64_t)k * 7 + j, R.qd[j]);
+      }
     }
+    if constexpr (ACC) tk_lane += cfg.dt;
   }
-  if (active) ra.store(avg_out, 0, sumsq / (T)(H * 7));
+  if (active) avg_out[r] = sumsq / (T)(H * 7);
 }
 
 // ---------------------------------------------------------------------------- sphere kinematics
@@ -1466,6 +1505,8 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
     if (e == hipSuccess) e = hipMemcpy(h->dcfg, &d, sizeof(d), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) return fail(h, MRF_E_DEVICE, std::string("config upload: ") + hipGetErrorString(e));
+  if (hipMalloc(&h->clock_probe, 8 * sizeof(long long)) != hipSuccess || hipMemset(h->clock_probe, 0, 8 * sizeof(long long)) != hipSuccess)
+    return fail(h, MRF_E_DEVICE, "clock probe buffer");
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
   // measured crossover (tools/crossover.py, 3-Panda H=30, r01 v4): cooperative 0.35-0.42 ms up to one round of 4 waves
@@ -1484,6 +1525,7 @@ void mrf_destroy(mrf_handle* h) {
   if (h->graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)h->graph_exec);
   if (h->own_stream) (void)hipStreamDestroy((hipStream_t)h->own_stream);
   if (h->dcfg) (void)hipFree(h->dcfg);
+  if (h->clock_probe) (void)hipFree(h->clock_probe);
   delete h;
 }
 
@@ -1562,10 +1604,32 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
     using LS = decltype(cl);
     if (is_link_origin_table(h->cfg))
       return launch(h, mrf::k_rollout_panda<T, LS, true>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
-                    (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+                    (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd,
+                    (long long*)h->clock_probe);
     return launch(h, mrf::k_rollout_panda<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
-                  (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+                  (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd,
+                  (long long*)h->clock_probe);
   });
+}
+
+int mrf_rollout_clock(mrf_handle* h, double* out, int32_t n) {
+  MRF_CHECK_READY(h);
+  if (!out || n < 1) return fail(h, MRF_E_ARG, "null/negative argument");
+  if (int rc = check_hip(h, hipDeviceSynchronize(), "hipDeviceSynchronize")) return rc;
+  long long st[8];
+  if (int rc = check_hip(h, hipMemcpy(st, h->clock_probe, sizeof(st), hipMemcpyDeviceToHost), "hipMemcpy")) return rc;
+  int wall_khz = 100000;
+  (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, h->device);
+  double vals[MRF_ROLLOUT_CLOCK_N] = {0, 0, 0, 0, (double)wall_khz * 1e-6};
+  for (int b = 0; b < 2; ++b) {
+    const double cycles = (double)(st[4 * b + 2] - st[4 * b + 0]), ticks = (double)(st[4 * b + 3] - st[4 * b + 1]);
+    if (ticks > 0 && cycles > 0) {
+      vals[b] = cycles / ticks * (double)wall_khz * 1e-6;  // shader cycles per wall-clock tick x tick rate [GHz]
+      vals[2 + b] = ticks / (double)wall_khz;              // lifetime of that workgroup [ms]
+    }
+  }
+  for (int i = 0; i < n && i < MRF_ROLLOUT_CLOCK_N; ++i) out[i] = vals[i];
+  return MRF_OK;
 }
 
 int mrf_rollout_cartesian(mrf_handle* h, int64_t rows, const void* q0, const void* qdot0, const void* params,

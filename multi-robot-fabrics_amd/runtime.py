@@ -150,6 +150,15 @@ class FabricHandle:
         self._check(rc)
         return (avg, tq, tqd) if want_traj else avg
 
+    def rollout_clock(self):
+        """Shader clock of the last row-per-lane rollout launch, measured inside the kernel (mrf_rollout_clock; this
+        synchronises the device): dict with the clock seen by the first / last workgroup [GHz] and their lifetimes [ms]."""
+        v = (C.c_double * 5)()
+        self._check(self.lib.mrf_rollout_clock(self._h, v, 5))
+        ghz = [x for x in (v[0], v[1]) if x > 0]
+        return {"shader_ghz_first_workgroup": v[0], "shader_ghz_last_workgroup": v[1], "first_workgroup_ms": v[2],
+                "last_workgroup_ms": v[3], "wall_clock_ghz": v[4], "shader_ghz": sum(ghz) / len(ghz) if ghz else None}
+
     def rollout_cartesian(self, q0, qdot0, params, obst_x0, obst_v, obst_a, obst_r, want_traj=False, n_static=0,
                           stream=None):
         rows = q0.shape[1]

@@ -167,3 +167,47 @@ def other_robot_obstacles(cfg, batch, spheres_x, spheres_v=None, spheres_a=None)
                 orv[m + s, :, i] = cfg.sphere_radius[s]
             m += S
     return ox, ov, oa, orad
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json configs
+BASELINE_CONFIGS = ("C2", "C3", "C5", "CART")
+
+
+def baseline_config(name, scalar=abi.F64):
+    """The BASELINE.json configurations beside the bench headline (C4 = 3-Panda RF-CV H=30), built in ONE place for
+    bench.py's `configs` block, tools/prof_configs.py (the counter passes behind profiles/traffic.json) and the tests:
+        C2    2-Panda MRDF, no rollout, 10 collision spheres per robot      -> mrf_compute_action_coupled
+        C3    2-Panda Rollout Fabrics H=20, link-origin spheres             -> mrf_rollout
+        C5    8-Panda RF-CV H=50, 20 spheres per robot (config.c5_sphere_table, 140 obstacle spheres per robot) -> mrf_rollout
+        CART  3-Panda Cartesian rollout H=30, M=16 constant-velocity obstacle spheres per robot (the other
+              robots' link origins at the start state), no obstacle accelerations (FPC:33) -> mrf_rollout_cartesian
+    -> dict(cfg, kind, batch = keyword arguments of panda_batch, scenarios_per_cu_round, label)."""
+    if name == "C2":
+        cfg = _config.panda_config(n_robots=2, horizon=1, scalar=scalar)
+        links, offs = _config.sphere_offsets_per_link(2)          # 16 candidates; 10 of them, spread over links 2..8
+        keep = [2, 3, 4, 6, 8, 9, 10, 12, 14, 15]
+        _config.set_spheres(cfg, [links[i] for i in keep], [offs[i] for i in keep])
+        return dict(cfg=cfg, kind="action_coupled", batch=dict(x_min=0.15), label="2-Panda MRDF jointspace, 10 spheres/robot")
+    if name == "C3":
+        cfg = _config.panda_config(n_robots=2, horizon=20, scalar=scalar)
+        return dict(cfg=cfg, kind="rollout", batch={}, label="2-Panda RF H=20")
+    if name == "C5":
+        cfg = _config.panda_config(n_robots=8, horizon=50, scalar=scalar)
+        links, offs = _config.c5_sphere_table()
+        _config.set_spheres(cfg, links, offs)
+        cfg.goal_estimate_mask = 0xFE
+        return dict(cfg=cfg, kind="rollout", batch=dict(x_min=0.3, q_spread=0.15), label="8-Panda RF-CV H=50, 20 spheres/robot")
+    if name == "CART":
+        cfg = _config.panda_config(n_robots=3, horizon=30, scalar=scalar)
+        return dict(cfg=cfg, kind="rollout_cartesian", batch=dict(x_min=0.1), label="3-Panda Cartesian rollout H=30, M=16")
+    raise KeyError(f"unknown baseline configuration {name!r}: {BASELINE_CONFIGS}")
+
+
+def tiled_batch(cfg, n_scenarios, seed, unique=4096, **kw):
+    """A batch of n_scenarios scenarios whose first `unique` ones are drawn by panda_batch and then repeated: large timing
+    batches without minutes of host-side rejection sampling (the oracle spot checks look at the first scenarios)."""
+    N = cfg.n_robots
+    u = min(unique, n_scenarios)
+    b = panda_batch(cfg, u, seed=seed, **kw)
+    reps = -(-n_scenarios // u)
+    return {k: np.ascontiguousarray(np.tile(v, (1, reps))[:, :n_scenarios * N]) for k, v in b.items()}

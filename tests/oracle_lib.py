@@ -42,6 +42,8 @@ def use_library(path):
 
 def lib():
     global _lib
+    if _lib is None and os.environ.get("MRF_ORACLE_LIB"):      # another build of the same source (the sanitizer build)
+        _lib = C.CDLL(os.environ["MRF_ORACLE_LIB"])
     if _lib is None:
         src = os.path.join(ORACLE_DIR, "mrf_oracle.cpp")
         if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):

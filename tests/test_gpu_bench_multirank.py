@@ -31,6 +31,13 @@ def test_two_ranks_one_gpu_scenario_sharding():
     assert r["roofline"]["bound"] in ("valu_f64", "hbm") and r["roofline"]["frac"] > 0
     assert r["roofline"]["hbm_algorithmic"]["bound"] == "hbm"
     assert r["parity_spot_check"]["ok"], r["parity_spot_check"]
+    # what the MAX over ranks was taken of: every rank's elapsed time, kernel time, clock and device
+    pr = r["per_rank"]
+    assert len(pr["elapsed_s"]["all"]) == 2 and pr["elapsed_s"]["max"] >= pr["elapsed_s"]["min"] > 0
+    assert abs(pr["elapsed_s"]["max"] - r["ms_per_step"] * 3e-3) / pr["elapsed_s"]["max"] < 0.05
+    assert len(pr["rollout_kernel_ms"]["all"]) == 2 and len(pr["devices"]) == 2 and pr["distinct_devices"] == 1   # shared GPU
+    assert all(g is None or 0.5 < g < 3.5 for g in pr["shader_ghz"])
+    assert r["roofline"]["effective_clock_ghz"] == r["effective_clock_ghz"]
 
 
 def test_bare_launch_spawns_its_own_ranks():
@@ -52,6 +59,13 @@ def test_bare_launch_spawns_its_own_ranks():
     assert "error" not in peer, peer
     assert peer["config"]["robot_group_ranks"] == 2 and peer["config"]["robots_per_rank"] == [2, 1]
     assert peer["parity_vs_fused_kernel"]["ok"] and peer["roofline"]["bound"] == "xgmi_link"
+    # the block proves what ran: every rank's communicator as the library reports it, its device, its own time per rollout
+    assert [x["comm"]["transport"] for x in peer["ranks"]] == ["peer", "peer"]
+    assert [x["comm"]["world"] for x in peer["ranks"]] == [2, 2] and [x["comm"]["rank"] for x in peer["ranks"]] == [0, 1]
+    assert [x["comm"]["peer_buffers_mapped"] for x in peer["ranks"]] == [1, 1]
+    assert [(x["comm"]["robot_first"], x["comm"]["robot_count"]) for x in peer["ranks"]] == [(0, 2), (2, 1)]
+    assert peer["rollout_ms_per_rank"]["max"] >= peer["rollout_ms_per_rank"]["min"] > 0 and len(peer["devices"]) == 2
+    assert peer["rccl_ranks_seen"] is None
 
 
 def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
@@ -81,14 +95,15 @@ def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
 
 def test_stuck_secondary_block_cannot_take_the_headline_with_it():
     """The wall-clock guard around the robot-sharded block (bench.py run_guarded): with a guard far shorter than the
-    block, rank 0 still emits the scenario-sharded headline -- with an error marker in place of the block -- and every
-    rank leaves with exit code 0."""
+    block, rank 0 still emits the scenario-sharded headline -- with an error marker in place of the block -- and the run
+    ends with the distinct exit code bench.SHARD_TIMEOUT_RC (3): a hung exchange in processes that have touched the GPU
+    is not a clean run, but the line is there."""
     env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_BENCH_SHARD_TIMEOUT_S="0.01")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenarios", "2016"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])

@@ -40,6 +40,13 @@ def test_world1_matches_fused_rollout(transport, n_robots, horizon, n_scen, tabl
     sr = ShardedRollout(cfg, 0, 1, device_index=0, transport=transport, max_scenarios=n_scen)
     h = sr.backend.h
     assert h.comm_partition() == (0, n_robots)
+    # the communicator as it reports itself (mrf_comm_info): for RCCL what ncclCommCount / UserRank / CuDevice return
+    info = h.comm_info()
+    assert (info["transport"], info["rank"], info["world"], info["robot_first"], info["robot_count"]) == (transport, 0, 1, 0, n_robots)
+    if transport == "rccl":
+        assert (info["rccl_comm_count"], info["rccl_user_rank"]) == (1, 0) and info["rccl_device"] == info["hip_device"] == 0
+    else:
+        assert (info["rccl_comm_count"], info["rccl_user_rank"], info["peer_buffers_mapped"]) == (0, -1, 0)
     q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
     want_avg, tq, tqd = FabricHandle(cfg, 0).rollout(q, qd, prm, want_traj=True)
     for _ in range(2):
@@ -102,8 +109,9 @@ def test_plain_c_consumer_two_processes_one_gpu():
 
 def test_peer_timeout_is_loud_and_recoverable():
     """A peer that skips a rollout: the waiting rank's exchange times out (bounded), its rollout leaves q / qdot alone and
-    returns NaN, mrf_comm_status reports it; mrf_comm_reset on every rank between two barriers makes the group usable
-    again although the ranks had issued different numbers of rollouts (tests/timeout_worker.py)."""
+    returns NaN, mrf_comm_status reports it ON BOTH RANKS; mrf_comm_reset on every rank between two barriers makes the
+    group usable again although the ranks had issued different numbers of rollouts.  Then a peer that arrives late:
+    neither rank may return a finite result (tests/timeout_worker.py)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="400", MRF_PEER_DEVICE_SHARE="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "tests", "timeout_worker.py")]
@@ -112,4 +120,9 @@ def test_peer_timeout_is_loud_and_recoverable():
     ranks = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["ranks"]
     r0 = next(r for r in ranks if r["rank"] == 0)
     assert r0["status_raised"] is True and r0["avg_all_nan"] and r0["state_untouched"], r0
+    assert next(r for r in ranks if r["rank"] == 1)["peer_error_seen"] is True           # the error is the group's
     assert all(r["err_after_reset"] < 1e-9 for r in ranks), ranks
+    # a peer that arrives after the other rank gave up cannot return a finite result either; all rows or none are committed
+    for r in ranks:
+        assert r["late_peer"] == {"status_raised": True, "avg_all_nan": True, "state_untouched": True}, r
+    assert all(r["err_after_second_reset"] < 1e-9 for r in ranks), ranks

@@ -40,6 +40,13 @@ def main():
         report["avg_all_nan"] = bool(torch.isnan(avg).all())
         report["state_untouched"] = bool(torch.equal(q, q0) and torch.equal(qd, qd0))
     dist.barrier()
+    if rank == 1:                                     # the timeout is the GROUP's: rank 0 raised this rank's error word too
+        try:
+            h.comm_status()
+            report["peer_error_seen"] = False
+        except MrfError:
+            report["peer_error_seen"] = True
+    dist.barrier()
     h.comm_reset()
     dist.barrier()
     ref = FabricHandle(cfg, 0)
@@ -51,6 +58,29 @@ def main():
         h.comm_status()
         errs.append(float((avg - want).abs().max() / want.abs().max()))
     report["err_after_reset"] = max(errs)
+    # second failure, the other way round: rank 1 arrives LATE -- after rank 0 has given up -- and rolls out
+    # anyway.  Rank 0 stopped publishing and raised rank 1's error word, so rank 1 cannot return a finite result built on
+    # rank 0's stale spheres: both ranks get NaN, untouched state and a raising status.
+    dist.barrier()
+    if rank == 1:
+        import time
+        time.sleep(3.0 * float(os.environ.get("MRF_PEER_TIMEOUT_MS", "400")) * 1e-3)
+    q, qd = q0.clone(), qd0.clone()
+    avg = sr.rollout(q, qd, prm)
+    try:
+        h.comm_status()
+        raised = False
+    except MrfError:
+        raised = True
+    report["late_peer"] = {"status_raised": raised, "avg_all_nan": bool(torch.isnan(avg).all()),
+                           "state_untouched": bool(torch.equal(q, q0) and torch.equal(qd, qd0))}
+    dist.barrier()
+    h.comm_reset()                                    # second reset: epoch 2 of the sequence numbers
+    dist.barrier()
+    q, qd = q0.clone(), qd0.clone()
+    avg = sr.rollout(q, qd, prm)
+    h.comm_status()
+    report["err_after_second_reset"] = float((avg - want).abs().max() / want.abs().max())
     out = [None] * world
     dist.all_gather_object(out, report)
     if rank == 0:

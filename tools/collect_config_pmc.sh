@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_config_pmc.sh <tag>'): counter passes for bench.py's `configs` block
+# (C2, C3, C5, Cartesian rollout; tools/prof_configs.py launches them as bench.py does) -- separate rocprofv3 --pmc passes,
+# never combined with another trace domain -- and the traffic.json entries derived from them (tools/make_traffic.py).
+# Writes gpurun_out/profiles/<tag>_configs_pmc.json and <tag>_configs_traffic.json; copy what is to be judged into profiles/.
+tag=${1:-rXX}; dt=${2:-f64}
+root=$(pwd); out=$root/gpurun_out/cpmc_$tag
+mkdir -p $out $root/gpurun_out/profiles; cd /tmp; export TMPDIR=/tmp
+python3 $root/tools/prof_configs.py $dt > $out/prof_configs.txt 2>&1
+specs=""
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SMEM SQ_INSTS_VMEM" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
+  name=$(echo $pass | tr ' ' '+')
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/c_$name -- python3 $root/tools/prof_configs.py $dt > $out/c_$name.log 2>&1
+  specs="$specs $name=$out/c_$name"
+done
+python3 $root/tools/summarize_prof.py ${tag}_configs $out/none $root/gpurun_out/profiles $specs > $out/summary.log 2>&1
+pmc=$root/gpurun_out/profiles/${tag}_configs_pmc.json
+tj=$root/gpurun_out/profiles/${tag}_configs_traffic.json
+cus=$(python3 -c "import torch; print(torch.cuda.get_device_properties(0).multi_processor_count)")
+python3 $root/tools/make_traffic.py $pmc config_C2_${dt}_B65536 --horizon 1 --kernel-substring "k_action_coupled<" --out $tj >> $out/summary.log 2>&1
+python3 $root/tools/make_traffic.py $pmc config_C3_${dt}_B$((2*cus*4*32)) --horizon 20 --kernel-substring "k_rollout_panda<double, LS_reference, true>" --out $tj >> $out/summary.log 2>&1
+python3 $root/tools/make_traffic.py $pmc config_C5_${dt}_B$((2*cus*4*8)) --horizon 50 --kernel-substring "k_rollout_panda<double, LS_reference, false>" --out $tj >> $out/summary.log 2>&1
+python3 $root/tools/make_traffic.py $pmc config_CART_${dt}_B$((2*cus*4*21)) --horizon 30 --kernel-substring "k_rollout_cart_panda<" --out $tj >> $out/summary.log 2>&1
+tail -c 2500 $out/summary.log; cat $out/prof_configs.txt | cut -c1-400

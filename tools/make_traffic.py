@@ -2,7 +2,8 @@
 """Derives bench.py's roofline inputs from a PMC summary -- no hand copy.
 
 usage: make_traffic.py <profiles/TAG_pmc.json> <key> [--horizon H] [--kernel-substring k_rollout_panda] [--out profiles/traffic.json]
-  key: the traffic.json entry to (re)write, "rollout_<dtype>_N<N>_H<H>_B<B>" (what bench.py looks up)
+  key: the traffic.json entry to (re)write: "rollout_<dtype>_N<N>_H<H>_B<B>" (the headline, what bench.py looks up) or
+       "config_<NAME>_<dtype>_B<B>" (bench.py's `configs` block; --horizon = lane-steps per launch: H, or 1 for compute_action)
 
 From the kernel's entry in the PMC file (tools/summarize_prof.py: means over the full-batch dispatches of separate
 --pmc passes):
@@ -56,10 +57,14 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "traffic.json"))
     args = ap.parse_args()
     m = re.fullmatch(r"rollout_(f64|f32)_N(\d+)_H(\d+)_B(\d+)", args.key)
-    if not m:
-        raise SystemExit("key must look like rollout_f64_N3_H30_B129024")
-    dtype, H = m.group(1), int(m.group(3))
-    H = args.horizon or H
+    mc = re.fullmatch(r"config_([A-Za-z0-9]+)_(f64|f32)_B(\d+)", args.key)
+    if m:
+        dtype, H = m.group(1), int(m.group(3))
+        H = args.horizon or H
+    elif mc and args.horizon:
+        dtype, H = mc.group(2), args.horizon
+    else:
+        raise SystemExit("key must look like rollout_f64_N3_H30_B129024, or config_C3_f64_B65536 with --horizon")
     with open(args.pmc) as f:
         pmc = json.load(f)
     kernel = pick(pmc, args.kernel_substring)
