@@ -985,11 +985,12 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
   // measured (profiles/r04_experiments.json, H=30, M=16, f64): the uniform-base addressing pays without obstacle
   // accelerations (3.81 -> 3.72 ms, scratch 44 -> 20 B per lane); with them the allocator trades it for more scratch
   // (60 -> 84 B, 4.05 -> 4.19 ms), so that instantiation keeps the per-lane addresses
-  using Addr = std::conditional_t<ACC, LaneAddr<T>, RowAddr<T>>;
-  using Prm = std::conditional_t<ACC, PrmView<T>, PrmViewU<T>>;
+  constexpr bool LANE = ACC;
+  using Addr = std::conditional_t<LANE, LaneAddr<T>, RowAddr<T>>;
+  using Prm = std::conditional_t<LANE, PrmView<T>, PrmViewU<T>>;
   Addr addr;
   Prm P;
-  if constexpr (ACC) {
+  if constexpr (LANE) {
     addr = LaneAddr<T>{rows, r};
     P = PrmView<T>{prm, rows, r, {T(0), T(0), T(0)}, false};
   } else {
@@ -1015,14 +1016,12 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
     panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          // measured (tools/prof_kernels.py, H=30, M=16, f64): with accelerations the two-loop form is the faster one
-          // (3.91 ms against 4.07 ms), without them the single loop (3.81 ms against 3.95 ms)
+          // one pipelined loop over resident and streamed obstacles, or one loop each (-DMRF_CART_TWO_LOOPS): which one is
+          // faster has followed the register allocator from build to build (profiles/r04_experiments.json)
 #if defined(MRF_CART_TWO_LOOPS)
           constexpr bool two_loops = true;
-#elif defined(MRF_CART_ONE_LOOP)
-          constexpr bool two_loops = false;
 #else
-          constexpr bool two_loops = ACC;
+          constexpr bool two_loops = false;
 #endif
           if constexpr (RES && two_loops) {
             obstacles_resident<typename LS::Collision, ACC>(cfg, res, (int)threadIdx.x, nres, n_static, ov != nullptr,

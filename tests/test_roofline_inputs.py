@@ -20,19 +20,24 @@ def test_traffic_json_equals_its_sources():
         if key.startswith("_") or "kernel" not in rec:
             continue                                   # round-1 record kept for history (hand-entered then)
         m = re.fullmatch(r"rollout_(f64|f32)_N(\d+)_H(\d+)_B(\d+)", key)
-        assert m, key
+        mc = re.fullmatch(r"config_([A-Za-z0-9]+)_(f64|f32)_B(\d+)", key)       # bench.py's `configs` block
+        assert m or mc, key
+        dtype = m.group(1) if m else mc.group(2)
         with open(os.path.join(ROOT, rec["source"])) as f:
             pmc = json.load(f)
-        kernel = make_traffic.pick(pmc, "k_rollout_panda<")
-        want = make_traffic.derive(pmc[kernel], int(m.group(3)), m.group(1))
+        hits = [k for k in pmc if k.startswith(rec["kernel"]) and not k.startswith("_")]
+        assert len(hits) == 1, (key, hits)
+        kernel = hits[0]
+        want = make_traffic.derive(pmc[kernel], rec["horizon"], dtype)
         assert rec["bytes_per_launch"] == want["bytes_per_launch"], key
         assert rec["flops_per_unit"] == want["flops_per_unit"], key
         assert rec["kernel_source_sha256"] == pmc.get("_meta", {}).get("kernel_source_sha256"), key
-        # the batch in the key is the batch the counters were taken at: grid = waves * 64 lanes, 64 // N scenarios per wave
-        N, B = int(m.group(2)), int(m.group(4))
-        assert int(pmc[kernel]["SQ_WAVES"]) == -(-B // (64 // N)), key
+        if m:
+            # the batch in the key is the batch the counters were taken at: grid = waves * 64 lanes, 64 // N scenarios per wave
+            N, B = int(m.group(2)), int(m.group(4))
+            assert int(m.group(3)) == rec["horizon"] and int(pmc[kernel]["SQ_WAVES"]) == -(-B // (64 // N)), key
         checked += 1
-    assert checked >= 1
+    assert checked >= 5          # the headline and the four configurations of the `configs` block
 
 
 def test_kernel_source_hash_is_of_the_two_kernel_files():

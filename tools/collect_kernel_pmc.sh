@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/collect_kernel_pmc.sh <tag>'): counter evidence for every kernel behind
 # include/mrf.h EXCEPT the bench's rollout kernel (tools/collect_profiles.sh does that one): separate rocprofv3 --pmc passes
-# (never combined with another trace domain) over tools/prof_kernels.py (all kernels at the bench batch, f64) and
-# tools/prof_configs.py (the rollout kernel on C3 / C4 / C5, incl. the generic-table instantiation of C5).
+# (never combined with another trace domain) over tools/prof_kernels.py (all kernels at the bench batch, f64).  The BASELINE
+# configurations C2 / C3 / C5 / Cartesian have their own script, tools/collect_config_pmc.sh.
 # Writes gpurun_out/profiles/<tag>_kernels_pmc.json (per kernel: FETCH_SIZE / WRITE_SIZE in KiB, instruction and wait
 # counters, registers, LDS, scratch) and <tag>_per_kernel_f64.json with measured-vs-algorithmic bytes per kernel.
 tag=${1:-rXX}
@@ -10,18 +10,12 @@ root=$(pwd); out=$root/gpurun_out/kpmc_$tag
 mkdir -p $out $root/gpurun_out/profiles; cd /tmp; export TMPDIR=/tmp
 python3 $root/tools/prof_kernels.py f64 > $out/prof_kernels.txt 2>&1
 cp $root/gpurun_out/prof_kernels_f64.json $out/prof_kernels_f64.json
-specs=""; specs_c=""
+specs=""
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | tr ' ' '+')
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/k_$name -- python3 $root/tools/prof_kernels.py f64 > $out/k_$name.log 2>&1
   specs="$specs $name=$out/k_$name"
 done
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
-  name=$(echo $pass | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/c_$name -- python3 $root/tools/prof_configs.py f64only C5 > $out/c_$name.log 2>&1
-  specs_c="$specs_c $name=$out/c_$name"
-done
 python3 $root/tools/summarize_prof.py ${tag}_kernels $out/none $root/gpurun_out/profiles $specs > $out/summary_k.log 2>&1
-python3 $root/tools/summarize_prof.py ${tag}_configs $out/none $root/gpurun_out/profiles $specs_c > $out/summary_c.log 2>&1
 python3 $root/tools/kernel_byte_ratios.py $root/gpurun_out/profiles/${tag}_kernels_pmc.json $out/prof_kernels_f64.json > $root/gpurun_out/profiles/${tag}_per_kernel_f64.json 2> $out/ratios.err
 tail -c 1500 $root/gpurun_out/profiles/${tag}_per_kernel_f64.json
