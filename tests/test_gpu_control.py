@@ -260,3 +260,70 @@ def test_nonfinite_rollout_signal_is_counted():
     for _ in range(4):
         h.deadlock_step(dl, x_ee, avg, prm, st, goal)
     assert st[abi.DL_NONFINITE].tolist() == [0, 4, 0]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_episode_with_cartesian_rollouts_equals_the_stepwise_calls(use_graph):
+    """mrf_episode_set_rollout(MRF_ROLLOUT_CARTESIAN): the control step takes its velocity signal from
+    mrf_rollout_cartesian_coupled (the Cartesian driver's rollouts, EXC:366-399) instead of the coupled joint-space
+    rollout.  The episode -- plain launches and the replayed graph -- equals the same stages called one by one."""
+    N, B, STEPS = 3, 9, 6
+    cfg_act = config.panda_config(n_robots=N, horizon=1)
+    links, offs = config.sphere_offsets_per_link(2)
+    config.set_spheres(cfg_act, links, offs)
+    cfg_roll = cfg_act.copy()
+    cfg_roll.horizon = 4
+    batch = scenarios.panda_batch(cfg_act, B, seed=13, qd_spread=0.2)
+    ha, hr = FabricHandle(cfg_act, 0), FabricHandle(cfg_roll, 0)
+    q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    loop = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=True, apply_estimate=False, use_graph=use_graph,
+                       cartesian_rollouts=True)
+    jloop = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=True, apply_estimate=False, use_graph=use_graph)
+    # the same stages by hand
+    sq, sqd = q.clone(), qd.clone()
+    work = torch.empty_like(prm)
+    dl = ha.deadlock_config()
+    st, goal = hr.deadlock_state(B)
+    for _ in range(STEPS):
+        x_ee = hr.control_prepare(sq, sqd, prm, work, apply_estimate=False)
+        avg = hr.rollout_cartesian_coupled(sq, sqd, work)
+        hr.deadlock_step(dl, x_ee, avg, work, st, goal)
+        act = ha.compute_action_coupled(sq, sqd, work, use_accel=False)
+        ha.apply_action(sq, sqd, act, config.PANDA_VEL_LIMITS, stop_margin=1e-3)
+    loop.run(STEPS)
+    torch.cuda.synchronize()
+    assert torch.equal(loop.q, sq) and torch.equal(loop.qdot, sqd) and torch.equal(loop.avg, avg)
+    # and it is not the joint-space rollout's signal (the two rollouts predict different things)
+    jloop.run(STEPS)
+    assert not torch.equal(jloop.avg, loop.avg)
+    # the kind travels with the ROLLOUT handle and is part of the cached graph's key: switching back replays nothing stale
+    loop2 = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, deadlock=True, apply_estimate=False, use_graph=use_graph,
+                        cartesian_rollouts=True)
+    loop2.run(STEPS)
+    assert torch.equal(loop2.q, sq)
+
+
+def test_rollout_clock_probe():
+    """mrf_rollout_clock: zeros before any row-per-lane rollout; afterwards the shader clock stamped by the kernel's
+    first and last workgroup -- a physical clock (between 0.5 and 3.5 GHz), lifetimes shorter than the launch."""
+    cfg = config.panda_config(n_robots=3, horizon=10)
+    cfg.kernel_select = 1
+    h = FabricHandle(cfg, 0)
+    c0 = h.rollout_clock()
+    assert c0["shader_ghz"] is None and c0["first_workgroup_ms"] == 0.0 and abs(c0["wall_clock_ghz"] - 0.1) < 0.05
+    batch = scenarios.panda_batch(cfg, 5000, seed=4)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    args = [h.tensor(batch[k]) for k in ("q", "qdot", "params")]
+    h.rollout(*args)
+    e0.record()
+    h.rollout(*args)
+    e1.record()
+    c = h.rollout_clock()
+    assert 0.5 < c["shader_ghz_first_workgroup"] < 3.5 and 0.5 < c["shader_ghz_last_workgroup"] < 3.5
+    assert 0 < c["first_workgroup_ms"] <= e0.elapsed_time(e1) * 1.05 and 0 < c["last_workgroup_ms"] <= e0.elapsed_time(e1) * 1.05
+
+
+def test_comm_info_without_a_communicator():
+    h = FabricHandle(config.panda_config(n_robots=2, horizon=2), 0)
+    info = h.comm_info()
+    assert info["transport"] == "none" and info["world"] == 0 and info["rccl_comm_count"] == 0 and info["hip_device"] == 0
