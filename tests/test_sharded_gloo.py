@@ -158,3 +158,29 @@ def test_single_rank_needs_no_process_group(oracle):
     avg = sr.rollout(q, qd, prm)
     want_avg, _, _ = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"])
     assert np.abs(avg.numpy() - want_avg).max() < 1e-13
+
+
+def _agree_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        first = sharded.agree_on_error(None, world)                                # nobody failed: nobody raises
+        second = sharded.agree_on_error("exchange buffer" if rank == 2 else None, world)   # ONE rank failed: all hear of it
+        with open(os.path.join(out_dir, f"agree{rank}.txt"), "w") as f:
+            f.write(f"{first}|{second}")
+        dist.barrier()                                                             # everybody is still in step afterwards
+    finally:
+        dist.destroy_process_group()
+
+
+def test_errors_are_agreed_over_the_world(tmp_path):
+    """with unequal robot groups ([3, 1], [3, 3, 2]) an error that only one group hears of leaves the others in
+    the next world-wide collective.  sharded.agree_on_error gathers the ranks' error texts over the WORLD: either every
+    rank raises or none does (used after transport setup and after mrf_comm_status in the bench)."""
+    world = 4
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        first, second = open(os.path.join(str(tmp_path), f"agree{r}.txt")).read().split("|")
+        assert first == "None" and second == "rank 2: exchange buffer"
+    assert sharded.agree_on_error("alone", 1) == "alone"                            # a single process: nothing to agree on
