@@ -76,3 +76,39 @@ def test_collision_mask_in_the_cooperative_kernels_with_five_robots(oracle):
     h = FabricHandle(cfg, 0)
     avg, tq, tqd = h.rollout(*(h.tensor(b[k]) for k in ("q", "qdot", "params")), want_traj=True)
     assert rel(tqd.cpu().numpy(), want_qd) < 1e-9 and rel(avg.cpu().numpy(), want_avg) < 1e-9
+
+
+def test_rollout_cartesian_coupled_edge_cases():
+    """mrf_rollout_cartesian_coupled: an empty batch is a no-op, ragged row counts and missing arrays are refused, the
+    planar model is refused, and the float32 instantiation agrees with the float64 one to float32 accuracy on a
+    well-conditioned batch."""
+    import ctypes as C
+    from multi_robot_fabrics_amd.runtime import MrfError
+    cfg = config.panda_config(n_robots=2, horizon=4)
+    links, offs = config.sphere_offsets_per_link(2)
+    config.set_spheres(cfg, links, offs)
+    batch = scenarios.panda_batch(cfg, 12, seed=9, x_min=0.2)
+    h = FabricHandle(cfg, 0)
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    empty = h.rollout_cartesian_coupled(q[:, :0].contiguous(), qd[:, :0].contiguous(), prm[:, :0].contiguous())
+    assert empty.shape == (0,)
+    with pytest.raises(MrfError):
+        h.rollout_cartesian_coupled(q[:, :3].contiguous(), qd[:, :3].contiguous(), prm[:, :3].contiguous())      # 3 rows, 2 robots
+    rc = h.lib.mrf_rollout_cartesian_coupled(h._h, 12, C.c_void_p(q.data_ptr()), None, C.c_void_p(prm.data_ptr()),
+                                             C.c_void_p(q.data_ptr()), None, None, None)
+    assert rc == abi_status("MRF_E_ARG")
+    hp = FabricHandle(config.planar3_config(n_robots=2), 0)
+    z = torch.zeros((3, 2), dtype=torch.float64, device="cuda")
+    rc = hp.lib.mrf_rollout_cartesian_coupled(hp._h, 1, C.c_void_p(z.data_ptr()), C.c_void_p(z.data_ptr()),
+                                              C.c_void_p(z.data_ptr()), C.c_void_p(z.data_ptr()), None, None, None)
+    assert rc == abi_status("MRF_E_CONFIG")
+    want = h.rollout_cartesian_coupled(q, qd, prm)
+    cfg32 = cfg.copy()
+    cfg32.scalar = abi.F32
+    h32 = FabricHandle(cfg32, 0)
+    got = h32.rollout_cartesian_coupled(*(h32.tensor(batch[k]) for k in ("q", "qdot", "params")))
+    assert torch.allclose(got.double(), want, rtol=2e-3, atol=1e-5)
+
+
+def abi_status(name):
+    return {v: k for k, v in abi.STATUS_TEXT.items()}[name]
