@@ -433,6 +433,20 @@ int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scenarios, const void
 #define MRF_ROLLOUT_CARTESIAN 1
 int mrf_episode_set_rollout(mrf_handle* h_rollout, int32_t kind);
 
+/* Attaches a recorder to an action handle: every control step of mrf_episode_run on it then also stores, at index
+ * i = *step_counter (nothing once i >= capacity; the counter is advanced by the step itself), what a host loop would
+ * otherwise read back after every step -- so that any number of steps can be queued back to back:
+ *   q_hist  [capacity][dof][rows]    joint positions after the step                                   (or NULL)
+ *   sm_hist [capacity][rows] int32   state-machine states of the step (pick-and-place attached, else the sm_state argument) (or NULL)
+ *   t_begin, t_end [capacity] int64  the device's constant-rate wall clock (s_memrealtime ticks; rate: mrf_rollout_clock
+ *                                    out[4]) when the first kernel of the step started / when its last kernel ran   (or NULL)
+ *   done_at [rows] int32             first step index at which the row's state equalled done_state; the caller
+ *                                    initialises it to -1                                                (or NULL)
+ * All arrays are caller-owned device memory that must outlive the episodes; step_counter is int32[1].  capacity <= 0 or a
+ * NULL counter detaches. */
+int mrf_episode_set_recorder(mrf_handle* h_action, void* q_hist, int32_t* sm_hist, int64_t* t_begin, int64_t* t_end,
+                             int32_t* done_at, int32_t* step_counter, int32_t capacity, int32_t done_state);
+
 /* n_steps control steps on the device.  h_rollout may be NULL (no Rollout Fabrics, no deadlock logic: plain MRDF);
  * dl may be NULL (rollouts monitored, no deadlock logic).  Work buffers are caller-owned:
  *   params_work [MRF_NPARAM][rows]  x_ee_work [3][rows]  avg_work [rows]  action_out [dof][rows] (last step's action)

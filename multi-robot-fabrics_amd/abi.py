@@ -82,7 +82,7 @@ EXPORTS = [
     "mrf_episode_run",
     "mrf_compute_action_host", "mrf_rollout_host", "mrf_rollout_cartesian_host", "mrf_fk_spheres_host",
     "mrf_default_state_machine_config", "mrf_state_machine_config_sizeof", "mrf_state_machine_init", "mrf_state_machine_step",
-    "mrf_episode_set_pick_place", "mrf_rollout_cartesian_coupled", "mrf_episode_set_rollout", "mrf_rollout_clock",
+    "mrf_episode_set_pick_place", "mrf_rollout_cartesian_coupled", "mrf_episode_set_rollout", "mrf_rollout_clock", "mrf_episode_set_recorder",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
     "mrf_comm_info", "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
 ]
@@ -218,6 +218,9 @@ def load_library(path=None):
         lib.mrf_rollout_cartesian_coupled.restype = C.c_int
         lib.mrf_episode_set_rollout.argtypes = [vp, i32]
         lib.mrf_episode_set_rollout.restype = C.c_int
+    if not (any_abi and not hasattr(lib, "mrf_episode_set_recorder")):
+        lib.mrf_episode_set_recorder.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32]
+        lib.mrf_episode_set_recorder.restype = C.c_int
     if not (any_abi and not hasattr(lib, "mrf_rollout_clock")):
         lib.mrf_rollout_clock.argtypes = [vp, C.POINTER(C.c_double), i32]
         lib.mrf_rollout_clock.restype = C.c_int

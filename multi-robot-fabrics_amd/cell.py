@@ -6,8 +6,10 @@ evaluates the Rollout Fabrics, the deadlock logic and one `compute_action` per r
 the GPU: `PandaCell` owns the state of `scenes` independent copies of the cell (N robots each) and advances them with
 runtime.ControlLoop -- one replayed HIP graph per control step (mrf_episode_run): hand FK, pick-and-place state machine,
 RF-CV goal estimate, Rollout Fabrics (coupled joint-space or per-robot Cartesian), deadlock logic, compute_action of the
-main and of the grasp planner, gripper command, velocity integration.  The host only records: per-step device time
-(HIP events), the state-machine states, joint snapshots for the clearance statistics -- in chunks, never inside a step.
+main and of the grasp planner, gripper command, velocity integration -- and the step's own record (joint positions,
+state-machine states, who is done since when, wall-clock stamps at its first and after its last kernel;
+mrf_episode_set_recorder).  Steps are queued a chunk at a time with no host work in between; the host reads the record
+after a chunk.
 
 What stands in for the simulator: joints integrate their velocity command exactly (urdfenvs 'vel'
 mode), finger joints likewise between their stops, a cube travels with a closed gripper (mrf_state_machine_config.model
@@ -183,7 +185,7 @@ class EpisodeLog:
             "states_visited": [sorted(set(int(v) for v in self.states[:, scene, i])) for i in range(cell.N)],
             "time_in_deadlock_steps": int(self.deadlock_steps[scene]) if self.deadlock_steps is not None else 0,
             "q_final": self.q_hist[-1].view(7, cell.scenes, cell.N)[:, scene].T.cpu().numpy() if self.steps else None,
-            "solver_time_is": "device time of one control step (HIP events around the replayed graph)",
+            "solver_time_is": "device time of one control step: wall-clock stamps of its first and after its last kernel",
         })
         return res
 
@@ -285,43 +287,37 @@ class PandaCell:
 
     # -- stepping -----------------------------------------------------------------------------------------------------
     def run(self, n_steps, chunk=64, stop_when_done=True, history_limit_bytes=1 << 30):
-        """Up to n_steps control steps of every scene; stops at the end of the chunk in which every robot of every scene
-        has reported DONE and truncates the record to that step (the reference leaves its loop there, EXJ:311-312)."""
+        """Up to n_steps control steps of every scene, queued `chunk` at a time with no host work in between: the steps
+        record themselves (mrf_episode_set_recorder: joint positions, state-machine states, first-DONE step per row,
+        wall-clock stamps at the first and after the last kernel of every step).  Stops after the chunk in which every
+        robot of every scene has reported DONE and truncates the record to that step (the reference leaves its loop
+        there, EXJ:311-312)."""
         loop, N, B = self.loop, self.N, self.scenes
         rows = B * N
         dev = self.ha.device
         n_steps = int(n_steps)
         if n_steps * rows * 7 * loop.q.element_size() > history_limit_bytes:
             raise MrfError("joint history would exceed history_limit_bytes: run fewer steps per call or fewer scenes")
-        q_hist = torch.empty((n_steps, 7, rows), dtype=loop.q.dtype, device=dev)
-        st_hist = torch.empty((n_steps, rows), dtype=torch.int32, device=dev)
-        done_at = torch.full((rows,), -1, dtype=torch.int32, device=dev)
-        solver, wall = [], []
+        rec = loop.attach_recorder(n_steps, done_state=DONE)
+        tick_s = 1e-9 / self.ha.rollout_clock()["wall_clock_ghz"]          # seconds per tick of the device's wall clock
+        wall = []
         w = 0
         while w < n_steps:
             n = min(chunk, n_steps - w)
-            marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
             t0 = time.perf_counter()
-            for k, (e0, e1) in enumerate(marks):
-                e0.record()
-                loop.run(1)
-                e1.record()
-                state = loop.sm_state[abi.SM_STATE]
-                st_hist[w + k].copy_(state)
-                q_hist[w + k].copy_(loop.q)
-                done_at = torch.where((state == DONE) & (done_at < 0), torch.full_like(done_at, w + k), done_at)
+            loop.run(n)
             torch.cuda.synchronize(dev)
-            per_step_wall = (time.perf_counter() - t0) / n
-            solver += [1e-3 * e0.elapsed_time(e1) for e0, e1 in marks]
-            wall += [per_step_wall] * n
+            wall += [(time.perf_counter() - t0) / n] * n
             w += n
-            if stop_when_done and bool((done_at >= 0).all()):
-                w = int(done_at.max())          # the step at which the last robot reported DONE: nothing is recorded past it
+            if stop_when_done and bool((rec["done_at"] >= 0).all()):
+                w = int(rec["done_at"].max())   # the step at which the last robot reported DONE: nothing is kept past it
                 break
+        loop.recorder = None
+        solver = (rec["t_end"][:w] - rec["t_begin"][:w]).double().cpu().numpy() * tick_s
         picked = loop.sm_state[abi.SM_PICKED].view(B, N).cpu().numpy()
         failed = loop.sm_state[abi.SM_FAILED].view(B, N).cpu().numpy()
         dl = loop.dl_state
-        return EpisodeLog(self, w, np.asarray(solver[:w], dtype=float), np.asarray(wall[:w], dtype=float),
-                          done_at.view(B, N).cpu().numpy(), st_hist[:w].view(w, B, N).cpu().numpy(), q_hist[:w], picked, failed,
+        return EpisodeLog(self, w, solver, np.asarray(wall[:w], dtype=float), rec["done_at"].view(B, N).cpu().numpy(),
+                          rec["sm_hist"][:w].view(w, B, N).cpu().numpy(), rec["q_hist"][:w], picked, failed,
                           dl[abi.DL_TIME_IN_DEADLOCK].cpu().numpy() if dl is not None else None,
                           dl[abi.DL_NONFINITE].cpu().numpy() if dl is not None else None)

@@ -95,6 +95,35 @@ __global__ __launch_bounds__(64) void k_publish_obstacles(const DevCfg<T>* __res
       });
 }
 
+// Episode recorder (mrf_episode_set_recorder): what a host loop would otherwise read back after every control step --
+// joint positions, state-machine states, "who is done since when", and how long the step took -- written by the step
+// itself, so that n control steps can be queued back to back without the host in between.  k_step_begin stamps the
+// constant-rate wall clock (s_memrealtime) as the first kernel of a control step, k_step_record as its last one.
+__global__ void k_step_begin(const int32_t* __restrict__ counter, int capacity, int64_t* __restrict__ t_begin) {
+  const int i = *counter;
+  if (i < capacity) t_begin[i] = (int64_t)wall_clock64();
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_step_record(int64_t rows, int dof, int capacity, int done_state,
+                                                      const T* __restrict__ q, const int32_t* __restrict__ sm_state,
+                                                      T* __restrict__ q_hist, int32_t* __restrict__ sm_hist,
+                                                      int64_t* __restrict__ t_end, int32_t* __restrict__ done_at,
+                                                      int32_t* __restrict__ counter) {
+  const int i = *counter;  // every thread reads it before the (single) increment below: see the grid-wide ordering note
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < capacity && r < rows) {
+    if (q_hist)
+      for (int j = 0; j < dof; ++j) q_hist[((int64_t)i * dof + j) * rows + r] = q[j * rows + r];
+    const int s = sm_state ? sm_state[r] : 0;
+    if (sm_hist) sm_hist[(int64_t)i * rows + r] = s;
+    if (done_at && sm_state && s == done_state && done_at[r] < 0) done_at[r] = i;
+  }
+  if (r == 0 && i < capacity && t_end) t_end[i] = (int64_t)wall_clock64();
+}
+// the counter is advanced by its own one-thread launch AFTER k_step_record has completed (stream order), so that no
+// thread of the record kernel can see the incremented value
+__global__ void k_step_advance(int32_t* __restrict__ counter) { *counter += 1; }
+
 template <typename T>
 struct DeadlockCfg {
   T avg_vel_constant, dist_constant, w_follower, w_leader, goal_scale, ee_distance, follower_offset, min_goal_norm, z_floor;
@@ -662,6 +691,20 @@ int mrf_episode_set_rollout(mrf_handle* h_rollout, int32_t kind) {
 }
 
 
+
+int mrf_episode_set_recorder(mrf_handle* h, void* q_hist, int32_t* sm_hist, int64_t* t_begin, int64_t* t_end, int32_t* done_at,
+                             int32_t* step_counter, int32_t capacity, int32_t done_state) {
+  MRF_CHECK_READY(h);
+  if (capacity <= 0 || !step_counter) {
+    h->rec = mrf_handle::Recorder();
+    return MRF_OK;
+  }
+  h->rec.on = true;
+  h->rec.q_hist = q_hist; h->rec.sm_hist = sm_hist; h->rec.t_begin = t_begin; h->rec.t_end = t_end;
+  h->rec.done_at = done_at; h->rec.counter = step_counter; h->rec.capacity = capacity; h->rec.done_state = done_state;
+  return MRF_OK;
+}
+
 static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mrf_deadlock_config* dl, int apply_estimate,
                         const double* vel_limit, double stop_margin, void* q, void* qd, const void* prm_nom,
                         void* prm_work, const int32_t* sm, int32_t* dl_state, void* dl_goal, void* x_ee, void* avg,
@@ -669,6 +712,10 @@ static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mr
   const int64_t rows = n_scen * ha->cfg.n_robots;
   int rc;
   const mrf_handle::PickPlace& pp = ha->pp;
+  const mrf_handle::Recorder& rec = ha->rec;
+  if (rec.on && rec.t_begin &&
+      (rc = launch(ha, mrf::k_step_begin, dim3(1), dim3(1), (hipStream_t)st, (const int32_t*)rec.counter, (int)rec.capacity, rec.t_begin)))
+    return rc;
   if (hr || pp.on) {  // hand FK (+ RF-CV estimate), then the state machine's goals for the rows the estimate left alone
     mrf_handle* hp = hr ? hr : ha;
     const int est = hr ? apply_estimate : 0;
@@ -703,7 +750,19 @@ static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mr
     });
     if (rc) return rc;
   }
-  return mrf_apply_action(ha, rows, q, qd, act, vel_limit, stop_margin, st);
+  if ((rc = mrf_apply_action(ha, rows, q, qd, act, vel_limit, stop_margin, st))) return rc;
+  if (rec.on) {
+    dim3 block(256), grid((unsigned)((rows + 255) / 256));
+    rc = dispatch_scalar(ha, [&](auto t) {
+      using T = decltype(t);
+      return launch(ha, mrf::k_step_record<T>, grid, block, (hipStream_t)st, rows, 7, (int)rec.capacity, (int)rec.done_state,
+                    (const T*)q, (const int32_t*)(pp.on ? pp.sm_state : sm), (T*)rec.q_hist, rec.sm_hist, rec.t_end, rec.done_at,
+                    rec.counter);
+    });
+    if (rc) return rc;
+    if ((rc = launch(ha, mrf::k_step_advance, dim3(1), dim3(1), (hipStream_t)st, rec.counter))) return rc;
+  }
+  return MRF_OK;
 }
 
 int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_steps, const mrf_deadlock_config* dl,
@@ -761,6 +820,7 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
                             (uint64_t)(uintptr_t)(hr ? hr->cart_work : nullptr)};
   key.append((const char*)ident, sizeof(ident));
   key.append((const char*)&ha->pp, sizeof(ha->pp));  // attached pick-and-place buffers and constants
+  key.append((const char*)&ha->rec, sizeof(ha->rec));  // attached recorder
   key.append((const char*)&dlc, sizeof(dlc));
   key.append((const char*)vel_limit, sizeof(double) * MRF_DOF_MAX);
   key.append((const char*)&stop_margin, sizeof(stop_margin));

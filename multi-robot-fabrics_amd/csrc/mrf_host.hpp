@@ -35,6 +35,18 @@ struct mrf_handle {
     uint64_t grasp_serial = 0;
     void* action_grasp = nullptr;
   } pp;
+  // episode recorder attached by mrf_episode_set_recorder (mrf_control.hip); all caller-owned device arrays
+  struct Recorder {
+    bool on = false;
+    void* q_hist = nullptr;
+    int32_t* sm_hist = nullptr;
+    int64_t* t_begin = nullptr;
+    int64_t* t_end = nullptr;
+    int32_t* done_at = nullptr;
+    int32_t* counter = nullptr;
+    int32_t capacity = 0;
+    int32_t done_state = 0;
+  } rec;
   // mrf_rollout_cartesian_coupled (mrf_control.hip): obstacle arrays assembled on the device, grown on demand (never
   // inside a stream capture: mrf_episode_run sizes them before it captures)
   void* clock_probe = nullptr;  // 8 x int64 written by the first / last workgroup of k_rollout_panda (mrf_rollout_clock)

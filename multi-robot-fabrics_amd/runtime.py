@@ -559,6 +559,22 @@ class ControlLoop:
             self.pick_place = True
         self.dl_cfg = h_action.deadlock_config() if (deadlock and h_rollout is not None) else None
         self.dl_state, self.dl_goal = (h_rollout.deadlock_state(self.n_scen) if self.dl_cfg is not None else (None, None))
+        self.recorder = None
+
+    def attach_recorder(self, capacity, done_state=10, keep_q=True):
+        """Have the control steps themselves record what a host loop would read back after every step
+        (mrf_episode_set_recorder), for the next `capacity` steps: -> dict of device tensors q_hist [capacity, dof, rows]
+        (None without keep_q), sm_hist [capacity, rows], t_begin / t_end [capacity] (wall-clock ticks), done_at [rows]
+        (first step with state == done_state, -1 before), counter [1].  run(n) can then queue n steps back to back."""
+        h, rows = self.ha, self.q.shape[1]
+        dev = h.device
+        self.recorder = dict(
+            q_hist=torch.empty((capacity, h.dof, rows), dtype=h.dtype, device=dev) if keep_q else None,
+            sm_hist=torch.zeros((capacity, rows), dtype=torch.int32, device=dev),
+            t_begin=torch.zeros((capacity,), dtype=torch.int64, device=dev), t_end=torch.zeros((capacity,), dtype=torch.int64, device=dev),
+            done_at=torch.full((rows,), -1, dtype=torch.int32, device=dev), counter=torch.zeros((1,), dtype=torch.int32, device=dev),
+            capacity=int(capacity), done_state=int(done_state))
+        return self.recorder
 
     def run(self, n_steps, stream=None):
         ha, hr = self.ha, self.hr
@@ -573,6 +589,12 @@ class ControlLoop:
             ha._check(ha.lib.mrf_episode_set_pick_place(ha._h, None, None, None, 0, None, None, None, None, None, None))
         if hr is not None:
             hr._check(hr.lib.mrf_episode_set_rollout(hr._h, self.rollout_kind))
+        rec = self.recorder
+        if rec is not None:
+            ha._check(ha.lib.mrf_episode_set_recorder(ha._h, p(rec["q_hist"]), p(rec["sm_hist"]), p(rec["t_begin"]), p(rec["t_end"]),
+                                                      p(rec["done_at"]), p(rec["counter"]), rec["capacity"], rec["done_state"]))
+        else:
+            ha._check(ha.lib.mrf_episode_set_recorder(ha._h, None, None, None, None, None, None, 0, 0))
         rc = ha.lib.mrf_episode_run(hr._h if hr is not None else None, ha._h, self.n_scen, int(n_steps),
                                     C.byref(self.dl_cfg) if self.dl_cfg is not None else None, int(self.apply_estimate),
                                     self.vel_limit, self.stop_margin, p(self.q), p(self.qdot), p(self.params),

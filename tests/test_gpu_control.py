@@ -327,3 +327,40 @@ def test_comm_info_without_a_communicator():
     h = FabricHandle(config.panda_config(n_robots=2, horizon=2), 0)
     info = h.comm_info()
     assert info["transport"] == "none" and info["world"] == 0 and info["rccl_comm_count"] == 0 and info["hip_device"] == 0
+
+
+def test_episode_recorder_equals_reading_back_after_every_step():
+    """mrf_episode_set_recorder: n control steps queued in ONE call record themselves -- joint positions, state-machine
+    states, first step with the 'done' state, wall-clock stamps -- exactly as a loop that reads the state back after every
+    single step sees them; steps beyond the capacity run but are not recorded."""
+    N, B, STEPS = 2, 5, 24
+    cfg_act = config.panda_config(n_robots=N, horizon=1)
+    cfg_roll = config.panda_config(n_robots=N, horizon=3)
+    batch = scenarios.panda_batch(cfg_act, B, seed=17, qd_spread=0.2)
+    ha, hr = FabricHandle(cfg_act, 0), FabricHandle(cfg_roll, 0)
+    q, qd, prm = (ha.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    sm = torch.zeros((B * N,), dtype=torch.int32, device="cuda")
+    sm[3] = 7                                                   # a fixed state pattern (no pick-and-place attached)
+    a = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, sm_state=sm)
+    b = ControlLoop(ha, hr, q, qd, prm, config.PANDA_VEL_LIMITS, sm_state=sm)
+    want = []
+    for _ in range(STEPS):
+        a.run(1)
+        want.append(a.q.clone())
+    rec = b.attach_recorder(STEPS, done_state=7)
+    b.run(STEPS + 4)                                            # four steps more than the recorder holds
+    torch.cuda.synchronize()
+    assert int(rec["counter"]) == STEPS + 4
+    assert torch.equal(rec["q_hist"], torch.stack(want))
+    assert torch.equal(rec["sm_hist"], sm[None].expand(STEPS, -1))
+    done = rec["done_at"].tolist()
+    assert done[3] == 0 and all(d == -1 for i, d in enumerate(done) if i != 3)
+    dt = (rec["t_end"] - rec["t_begin"]).cpu().numpy()
+    assert (dt > 0).all() and (dt < 1e6).all()                  # ticks of the 100 MHz wall clock: < 10 ms per step
+    assert (rec["t_begin"][1:] >= rec["t_end"][:-1]).all()      # steps do not overlap
+    # detaching: a loop without a recorder leaves the arrays alone
+    b.recorder = None
+    before = rec["counter"].clone()
+    b.run(2)
+    torch.cuda.synchronize()
+    assert torch.equal(rec["counter"], before)
