@@ -4,7 +4,9 @@
 //   k_control_prepare   hand FK + RF-CV goal estimate                        (EXJ:325-329, 346-348)
 //   k_deadlock          deadlock detection / resolution, one thread/scenario (deadlock_prevention.py:50-118)
 //   k_apply_action      clip + velocity integration + hard joint stops       (EXJ:452-453)
-//   mrf_episode_run     n control steps back to back, optionally as one replayed HIP graph
+//   mrf_episode_run     n control steps back to back, optionally as one replayed HIP graph; per step: k_step_head
+//                       (recorder stamp, hand FK + goal estimate, state machine) -> rollout -> k_deadlock -> the planners
+//                       -> k_step_tail (action selection, clip + integration, the step's record)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -15,14 +17,11 @@
 
 namespace mrf {
 
+// hand FK + RF-CV goal estimate of one row (mrf_control_prepare; also the head of a fused control step)
 template <typename T>
-__global__ __launch_bounds__(64) void k_control_prepare(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
-                                                         const T* __restrict__ q, const T* __restrict__ qd,
-                                                         const T* prm_nom, T* prm_work, int apply_estimate,
-                                                         T* __restrict__ x_ee) {
-  const DevCfg<T>& cfg = *cfgp;
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+__device__ __forceinline__ void prepare_row(const DevCfg<T>& cfg, int64_t rows, int64_t r, const T* __restrict__ q,
+                                            const T* __restrict__ qd, const T* prm_nom, T* prm_work, int apply_estimate,
+                                            T* __restrict__ x_ee) {
   const int li = (int)(r % cfg.n_robots);
   PandaState<T> R;
   load_state(rows, r, q, qd, R);
@@ -40,6 +39,15 @@ __global__ __launch_bounds__(64) void k_control_prepare(const DevCfg<T>* __restr
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(64) void k_control_prepare(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
+                                                         const T* __restrict__ q, const T* __restrict__ qd,
+                                                         const T* prm_nom, T* prm_work, int apply_estimate,
+                                                         T* __restrict__ x_ee) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  prepare_row<T>(*cfgp, rows, r, q, qd, prm_nom, prm_work, apply_estimate, x_ee);
+}
 
 // Obstacle assembly of the Cartesian rollouts on the device (compute_x_obsts_dyn_0, utils_fabrics_kinematics.py:3-33;
 // EXC:330-352): the dynamic obstacles of robot i are the configured spheres of all OTHER robots of its scenario, at
@@ -96,33 +104,14 @@ __global__ __launch_bounds__(64) void k_publish_obstacles(const DevCfg<T>* __res
 }
 
 // Episode recorder (mrf_episode_set_recorder): what a host loop would otherwise read back after every control step --
-// joint positions, state-machine states, "who is done since when", and how long the step took -- written by the step
-// itself, so that n control steps can be queued back to back without the host in between.  k_step_begin stamps the
-// constant-rate wall clock (s_memrealtime) as the first kernel of a control step, k_step_record as its last one.
-__global__ void k_step_begin(const int32_t* __restrict__ counter, int capacity, int64_t* __restrict__ t_begin) {
+// joint positions, state-machine states, "who is done since when", and how long the step took -- is written by the step
+// itself (k_step_head / k_step_tail below), so that n control steps can be queued back to back without the host in
+// between.  k_step_begin is the head's recorder part alone, for steps that have no head (plain MRDF without pick-and-place).
+__global__ void k_step_begin(int32_t* __restrict__ counter, int capacity, int64_t* __restrict__ t_begin) {
   const int i = *counter;
-  if (i < capacity) t_begin[i] = (int64_t)wall_clock64();
+  *counter = i + 1;
+  if (i < capacity && t_begin) t_begin[i] = (int64_t)wall_clock64();
 }
-template <typename T>
-__global__ __launch_bounds__(256) void k_step_record(int64_t rows, int dof, int capacity, int done_state,
-                                                      const T* __restrict__ q, const int32_t* __restrict__ sm_state,
-                                                      T* __restrict__ q_hist, int32_t* __restrict__ sm_hist,
-                                                      int64_t* __restrict__ t_end, int32_t* __restrict__ done_at,
-                                                      int32_t* __restrict__ counter) {
-  const int i = *counter;  // every thread reads it before the (single) increment below: see the grid-wide ordering note
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < capacity && r < rows) {
-    if (q_hist)
-      for (int j = 0; j < dof; ++j) q_hist[((int64_t)i * dof + j) * rows + r] = q[j * rows + r];
-    const int s = sm_state ? sm_state[r] : 0;
-    if (sm_hist) sm_hist[(int64_t)i * rows + r] = s;
-    if (done_at && sm_state && s == done_state && done_at[r] < 0) done_at[r] = i;
-  }
-  if (r == 0 && i < capacity && t_end) t_end[i] = (int64_t)wall_clock64();
-}
-// the counter is advanced by its own one-thread launch AFTER k_step_record has completed (stream order), so that no
-// thread of the record kernel can see the incremented value
-__global__ void k_step_advance(int32_t* __restrict__ counter) { *counter += 1; }
 
 template <typename T>
 struct DeadlockCfg {
@@ -261,16 +250,12 @@ struct SmCfg {
 
 // One thread per row; statement order follows get_state_machine_panda (SM:133-214) and get_gripper_action_panda (:66-86).
 template <typename T>
-__global__ __launch_bounds__(64) void k_state_machine(const DevCfg<T>* __restrict__ cfgp, int64_t rows, SmCfg<T> C,
-                                                       const T* __restrict__ x_ee, const T* __restrict__ start,
-                                                       const T* __restrict__ blocks, int n_block_arrays,
-                                                       T* __restrict__ q_grip, int32_t* __restrict__ st,
-                                                       T* __restrict__ sg, T* __restrict__ prm, int skip_mask,
-                                                       T* __restrict__ grip_act) {
+__device__ __forceinline__ void state_machine_row(const DevCfg<T>& cfg, int64_t rows, int64_t r, const SmCfg<T>& C,
+                                                  const T* __restrict__ x_ee, const T* __restrict__ start,
+                                                  const T* __restrict__ blocks, int n_block_arrays,
+                                                  T* __restrict__ q_grip, int32_t* __restrict__ st, T* __restrict__ sg,
+                                                  T* __restrict__ prm, int skip_mask, T* __restrict__ grip_act) {
 #pragma clang fp contract(off)  // plain mul/add as numpy evaluates them
-  const DevCfg<T>& cfg = *cfgp;
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
   int state = st[MRF_SM_STATE * rows + r], picked = st[MRF_SM_PICKED * rows + r], failed = st[MRF_SM_FAILED * rows + r];
   int t_grip = st[MRF_SM_T_GRIP * rows + r], closed = st[MRF_SM_GRIPPER * rows + r], stop = st[MRF_SM_STOP * rows + r];
   T goal[3], above_blk[3], x[3], s0[3], g[2];
@@ -388,6 +373,18 @@ __global__ __launch_bounds__(64) void k_state_machine(const DevCfg<T>* __restric
 }
 
 template <typename T>
+__global__ __launch_bounds__(64) void k_state_machine(const DevCfg<T>* __restrict__ cfgp, int64_t rows, SmCfg<T> C,
+                                                       const T* __restrict__ x_ee, const T* __restrict__ start,
+                                                       const T* __restrict__ blocks, int n_block_arrays,
+                                                       T* __restrict__ q_grip, int32_t* __restrict__ st,
+                                                       T* __restrict__ sg, T* __restrict__ prm, int skip_mask,
+                                                       T* __restrict__ grip_act) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  state_machine_row<T>(*cfgp, rows, r, C, x_ee, start, blocks, n_block_arrays, q_grip, st, sg, prm, skip_mask, grip_act);
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void k_state_machine_init(int64_t rows, const T* __restrict__ start,
                                                              int32_t* __restrict__ st, T* __restrict__ sg) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -401,33 +398,14 @@ __global__ __launch_bounds__(256) void k_state_machine_init(int64_t rows, const 
   sg[MRF_SM_WEIGHT * rows + r] = T(2);  // SM:11
 }
 
-// per-row action selection of the driver (EXJ:414-445): gripping / releasing rows stand still, descending rows take the
-// grasp planner's action
-template <typename T>
-__global__ __launch_bounds__(256) void k_select_action(int64_t rows, int dof, const int32_t* __restrict__ sm_state,
-                                                        const T* __restrict__ act_grasp, T* __restrict__ act) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const int s = sm_state[r];
-  if (s == 3 || s == 5) {
-    for (int j = 0; j < dof; ++j) act[j * rows + r] = T(0);
-  } else if (s == 2 && act_grasp) {
-    for (int j = 0; j < dof; ++j) act[j * rows + r] = act_grasp[j * rows + r];
-  }
-}
-
 template <typename T>
 struct VelLimits {
   T v[MRF_DOF_MAX];
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_apply_action(const DevCfg<T>* __restrict__ cfgp, int64_t rows, T* __restrict__ q,
-                                                       T* __restrict__ qd, T* __restrict__ act, VelLimits<T> L,
-                                                       T stop_margin) {
-  const DevCfg<T>& cfg = *cfgp;
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+__device__ __forceinline__ void apply_row(const DevCfg<T>& cfg, int64_t rows, int64_t r, T* __restrict__ q,
+                                          T* __restrict__ qd, T* __restrict__ act, const VelLimits<T>& L, T stop_margin) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     T a = act[j * rows + r];
@@ -438,6 +416,79 @@ __global__ __launch_bounds__(256) void k_apply_action(const DevCfg<T>* __restric
     qd[j * rows + r] = a;
     act[j * rows + r] = a;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_apply_action(const DevCfg<T>* __restrict__ cfgp, int64_t rows, T* __restrict__ q,
+                                                       T* __restrict__ qd, T* __restrict__ act, VelLimits<T> L,
+                                                       T stop_margin) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  apply_row<T>(*cfgp, rows, r, q, qd, act, L, stop_margin);
+}
+
+// ---------------------------------------------------------------------------- fused head and tail of a control step
+// mrf_episode_run's control step is a chain of small kernels around the rollout and the two planners; for a single cell
+// (one scenario) every launch costs more than its arithmetic, so the per-row stages before the rollout -- recorder begin
+// stamp, hand FK + goal estimate, pick-and-place state machine -- are ONE kernel, and the per-row stages after the
+// planners -- action selection by state, clip + integration, the step's record -- are another.  Same device functions
+// as the stand-alone entry points (mrf_control_prepare, mrf_state_machine_step, mrf_apply_action).
+struct RecView {
+  int32_t* counter;   // NULL: no recorder attached
+  int capacity, done_state;
+  int64_t* t_begin;
+  int64_t* t_end;
+  void* q_hist;
+  int32_t* sm_hist;
+  int32_t* done_at;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_step_head(const DevCfg<T>* __restrict__ cfgp, int64_t rows, const T* __restrict__ q,
+                                                   const T* __restrict__ qd, const T* prm_nom, T* prm_work,
+                                                   int apply_estimate, T* __restrict__ x_ee, int with_sm, SmCfg<T> C,
+                                                   const T* __restrict__ start, const T* __restrict__ blocks,
+                                                   int n_block_arrays, T* __restrict__ q_grip, int32_t* __restrict__ st,
+                                                   T* __restrict__ sg, int skip_mask, T* __restrict__ grip_act, RecView rec) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (rec.counter && r == 0) {  // the step takes its record index here; the tail of the same step reads counter - 1
+    const int i = *rec.counter;
+    *rec.counter = i + 1;
+    if (i < rec.capacity && rec.t_begin) rec.t_begin[i] = (int64_t)wall_clock64();
+  }
+  if (r >= rows) return;
+  prepare_row<T>(*cfgp, rows, r, q, qd, prm_nom, prm_work, apply_estimate, x_ee);
+  if (with_sm)
+    state_machine_row<T>(*cfgp, rows, r, C, x_ee, start, blocks, n_block_arrays, q_grip, st, sg, prm_work, skip_mask, grip_act);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_step_tail(const DevCfg<T>* __restrict__ cfgp, int64_t rows, T* __restrict__ q,
+                                                    T* __restrict__ qd, T* __restrict__ act, VelLimits<T> L, T stop_margin,
+                                                    const int32_t* __restrict__ select_state, const T* __restrict__ act_grasp,
+                                                    const int32_t* __restrict__ sm_state, RecView rec) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = rec.counter ? *rec.counter - 1 : 0;
+  if (r < rows) {
+    if (select_state) {  // EXJ:414-445: gripping / releasing rows stand still, descending rows take the grasp planner's action
+      const int s = select_state[r];
+      if (s == 3 || s == 5) {
+        for (int j = 0; j < 7; ++j) act[j * rows + r] = T(0);
+      } else if (s == 2 && act_grasp) {
+        for (int j = 0; j < 7; ++j) act[j * rows + r] = act_grasp[j * rows + r];
+      }
+    }
+    apply_row<T>(*cfgp, rows, r, q, qd, act, L, stop_margin);
+    if (rec.counter && i < rec.capacity) {
+      T* q_hist = (T*)rec.q_hist;
+      if (q_hist)
+        for (int j = 0; j < 7; ++j) q_hist[((int64_t)i * 7 + j) * rows + r] = q[j * rows + r];
+      const int s = sm_state ? sm_state[r] : 0;
+      if (rec.sm_hist) rec.sm_hist[(int64_t)i * rows + r] = s;
+      if (rec.done_at && sm_state && s == rec.done_state && rec.done_at[r] < 0) rec.done_at[r] = i;
+    }
+  }
+  if (rec.counter && r == 0 && i < rec.capacity && rec.t_end) rec.t_end[i] = (int64_t)wall_clock64();
 }
 
 }  // namespace mrf
@@ -458,6 +509,18 @@ mrf::DeadlockCfg<T> to_dev(const mrf_deadlock_config& c) {
   d.time_wait = c.time_wait; d.min_time_step = c.min_time_step; d.grasp_state = c.grasp_state;
   d.grasp_timeout = c.grasp_timeout;
   return d;
+}
+
+template <typename T>
+mrf::SmCfg<T> make_smcfg(const mrf_state_machine_config* sm, double dt) {
+  mrf::SmCfg<T> C;
+  C.reach_home = (T)sm->reach_home; C.reach_pregrasp = (T)sm->reach_pregrasp; C.reach_block = (T)sm->reach_block;
+  C.reach_lift = (T)sm->reach_lift; C.reach_drop = (T)sm->reach_drop; C.pregrasp_height = (T)sm->pregrasp_height;
+  C.lift_height = (T)sm->lift_height; C.grip_steps = (T)sm->grip_steps; C.open_tol = (T)sm->open_tol;
+  C.dropped_below_z = (T)sm->dropped_below_z; C.weight_high = (T)sm->weight_high; C.weight_low = (T)sm->weight_low;
+  C.open0 = (T)sm->gripper_open[0]; C.open1 = (T)sm->gripper_open[1]; C.v_close = (T)sm->v_close; C.v_open = (T)sm->v_open;
+  C.dt = (T)dt; C.nr_blocks = sm->nr_blocks; C.model = sm->model;
+  return C;
 }
 
 int need_panda_vel(mrf_handle* h, const char* what) {
@@ -568,13 +631,7 @@ int mrf_state_machine_step(mrf_handle* h, int64_t rows, const mrf_state_machine_
   dim3 block(64), grid((unsigned)((rows + 63) / 64));
   return dispatch_scalar(h, [&](auto t) {
     using T = decltype(t);
-    mrf::SmCfg<T> C;
-    C.reach_home = (T)sm->reach_home; C.reach_pregrasp = (T)sm->reach_pregrasp; C.reach_block = (T)sm->reach_block;
-    C.reach_lift = (T)sm->reach_lift; C.reach_drop = (T)sm->reach_drop; C.pregrasp_height = (T)sm->pregrasp_height;
-    C.lift_height = (T)sm->lift_height; C.grip_steps = (T)sm->grip_steps; C.open_tol = (T)sm->open_tol;
-    C.dropped_below_z = (T)sm->dropped_below_z; C.weight_high = (T)sm->weight_high; C.weight_low = (T)sm->weight_low;
-    C.open0 = (T)sm->gripper_open[0]; C.open1 = (T)sm->gripper_open[1]; C.v_close = (T)sm->v_close; C.v_open = (T)sm->v_open;
-    C.dt = (T)h->cfg.dt; C.nr_blocks = sm->nr_blocks; C.model = sm->model;
+    const mrf::SmCfg<T> C = make_smcfg<T>(sm, h->cfg.dt);
     return launch(h, mrf::k_state_machine<T>, grid, block, (hipStream_t)stream, (const mrf::DevCfg<T>*)h->dcfg, rows, C,
                   (const T*)x_ee, (const T*)start_goal, (const T*)blocks, (int)n_block_arrays, (T*)q_gripper_io, sm_state,
                   (T*)sm_goal, (T*)params_work, (int)skip_robot_mask, (T*)gripper_action_out);
@@ -712,21 +769,37 @@ static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mr
   const int64_t rows = n_scen * ha->cfg.n_robots;
   int rc;
   const mrf_handle::PickPlace& pp = ha->pp;
-  const mrf_handle::Recorder& rec = ha->rec;
-  if (rec.on && rec.t_begin &&
-      (rc = launch(ha, mrf::k_step_begin, dim3(1), dim3(1), (hipStream_t)st, (const int32_t*)rec.counter, (int)rec.capacity, rec.t_begin)))
-    return rc;
-  if (hr || pp.on) {  // hand FK (+ RF-CV estimate), then the state machine's goals for the rows the estimate left alone
+  const mrf_handle::Recorder& rc_ = ha->rec;
+  mrf::RecView rec;
+  std::memset(&rec, 0, sizeof(rec));
+  if (rc_.on) {
+    rec.counter = rc_.counter; rec.capacity = rc_.capacity; rec.done_state = rc_.done_state; rec.t_begin = rc_.t_begin;
+    rec.t_end = rc_.t_end; rec.q_hist = rc_.q_hist; rec.sm_hist = rc_.sm_hist; rec.done_at = rc_.done_at;
+  }
+  if (ha->cfg.model != MRF_MODEL_PANDA7 || ha->cfg.mode != MRF_MODE_VEL)
+    return fail(ha, MRF_E_CONFIG, "the control step integrates velocity commands of the panda7 model (mode 'vel')");
+  if (hr || pp.on) {
+    // head: [recorder begin] + hand FK (+ RF-CV estimate) + the state machine's goals for the rows the estimate left
+    // alone, one launch.  The estimate's constants are the rollout handle's.
     mrf_handle* hp = hr ? hr : ha;
     const int est = hr ? apply_estimate : 0;
-    if ((rc = mrf_control_prepare(hp, n_scen, q, qd, prm_nom, prm_work, est, x_ee, st))) return rc;
-    if (pp.on) {
-      if ((rc = mrf_state_machine_step(ha, rows, &pp.sm, x_ee, pp.start_goal, pp.blocks, pp.n_block_arrays, pp.q_gripper,
-                                       pp.sm_state, pp.sm_goal, prm_work, est ? hp->cfg.goal_estimate_mask : 0,
-                                       pp.gripper_action, st)))
-        return rc;
-      sm = pp.sm_state;  // row MRF_SM_STATE (the first `rows` entries)
-    }
+    if (pp.on && (pp.sm.nr_blocks < 1 || (pp.sm.model != 0 && pp.sm.model != 1)))
+      return fail(ha, MRF_E_CONFIG, "nr_blocks >= 1 and model in {0,1}");
+    dim3 block(64), grid((unsigned)((rows + 63) / 64));
+    rc = dispatch_scalar(ha, [&](auto t) {
+      using T = decltype(t);
+      mrf::SmCfg<T> C;
+      std::memset(&C, 0, sizeof(C));
+      if (pp.on) C = make_smcfg<T>(&pp.sm, ha->cfg.dt);
+      return launch(ha, mrf::k_step_head<T>, grid, block, (hipStream_t)st, (const mrf::DevCfg<T>*)hp->dcfg, rows, (const T*)q,
+                    (const T*)qd, (const T*)prm_nom, (T*)prm_work, (int)est, (T*)x_ee, (int)pp.on, C, (const T*)pp.start_goal,
+                    (const T*)pp.blocks, (int)pp.n_block_arrays, (T*)pp.q_gripper, pp.sm_state, (T*)pp.sm_goal,
+                    (int)(est ? hp->cfg.goal_estimate_mask : 0), (T*)pp.gripper_action, rec);
+    });
+    if (rc) return rc;
+    if (pp.on) sm = pp.sm_state;  // row MRF_SM_STATE (the first `rows` entries)
+  } else if (rec.counter) {
+    if ((rc = launch(ha, mrf::k_step_begin, dim3(1), dim3(1), (hipStream_t)st, rec.counter, rec.capacity, rec.t_begin))) return rc;
   }
   if (hr) {
     rc = hr->episode_rollout_kind == MRF_ROLLOUT_CARTESIAN
@@ -736,33 +809,22 @@ static int control_step(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, const mr
     if (dl && (rc = mrf_deadlock_step(hr, n_scen, dl, -1, x_ee, avg, sm, prm_work, dl_state, dl_goal, st))) return rc;
   }
   if ((rc = mrf_compute_action_coupled(ha, n_scen, q, qd, (hr || pp.on) ? prm_work : prm_nom, 0, nullptr, act, st))) return rc;
-  if (pp.on) {
-    if (pp.h_grasp && (rc = mrf_compute_action(pp.h_grasp, rows, q, qd, prm_work, 0, 0, nullptr, nullptr, nullptr, nullptr,
-                                              nullptr, pp.action_grasp, st))) {
-      if (ha->err.empty()) ha->err = pp.h_grasp->err;
-      return rc;
-    }
-    dim3 block(256), grid((unsigned)((rows + 255) / 256));
-    rc = dispatch_scalar(ha, [&](auto t) {
-      using T = decltype(t);
-      return launch(ha, mrf::k_select_action<T>, grid, block, (hipStream_t)st, rows, 7, (const int32_t*)pp.sm_state,
-                    (const T*)pp.action_grasp, (T*)act);
-    });
-    if (rc) return rc;
+  if (pp.on && pp.h_grasp &&
+      (rc = mrf_compute_action(pp.h_grasp, rows, q, qd, prm_work, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               pp.action_grasp, st))) {
+    if (ha->err.empty()) ha->err = pp.h_grasp->err;
+    return rc;
   }
-  if ((rc = mrf_apply_action(ha, rows, q, qd, act, vel_limit, stop_margin, st))) return rc;
-  if (rec.on) {
-    dim3 block(256), grid((unsigned)((rows + 255) / 256));
-    rc = dispatch_scalar(ha, [&](auto t) {
-      using T = decltype(t);
-      return launch(ha, mrf::k_step_record<T>, grid, block, (hipStream_t)st, rows, 7, (int)rec.capacity, (int)rec.done_state,
-                    (const T*)q, (const int32_t*)(pp.on ? pp.sm_state : sm), (T*)rec.q_hist, rec.sm_hist, rec.t_end, rec.done_at,
-                    rec.counter);
-    });
-    if (rc) return rc;
-    if ((rc = launch(ha, mrf::k_step_advance, dim3(1), dim3(1), (hipStream_t)st, rec.counter))) return rc;
-  }
-  return MRF_OK;
+  // tail: action selection by state (EXJ:414-445) + clip / integration (EXJ:452-453) + the step's record, one launch
+  dim3 block(256), grid((unsigned)((rows + 255) / 256));
+  return dispatch_scalar(ha, [&](auto t) {
+    using T = decltype(t);
+    mrf::VelLimits<T> L;
+    for (int j = 0; j < MRF_DOF_MAX; ++j) L.v[j] = (T)vel_limit[j];
+    return launch(ha, mrf::k_step_tail<T>, grid, block, (hipStream_t)st, (const mrf::DevCfg<T>*)ha->dcfg, rows, (T*)q, (T*)qd,
+                  (T*)act, L, (T)stop_margin, (const int32_t*)(pp.on ? pp.sm_state : nullptr), (const T*)pp.action_grasp,
+                  (const int32_t*)sm, rec);
+  });
 }
 
 int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_steps, const mrf_deadlock_config* dl,
