@@ -1,93 +1,49 @@
 #!/usr/bin/env python3
-"""The reference's examples/example_pointmasses_dynamic.py through the mirrored classes: four point-mass robots, six
-static scene spheres and -- unlike the static twin -- the other three robots as DYNAMIC obstacles of dimension 2
-(set_planner_point :101-130: number_dynamic_obstacles = n_robots - 1, dynamic_obstacle_dimension = 2), passed with the
-reference's per-index keyword names x_obst_dynamic_j / xdot_obst_dynamic_j / xddot_obst_dynamic_j /
-radius_obst_dynamic_j (run_point_example :183-212; accelerations zero: "no dependence on fabrics of others").
-The gym simulator is replaced by arithmetic (acceleration-controlled point masses, dt = 0.01), as in
-example_pointmasses_static.py, whose remarks on creeping contact apply here too.
+"""The arena of example_pointmasses_static.py with the other three robots as MOVING obstacles: every robot's fabric gets
+their positions and velocities in the plane (dynamic obstacle leaves of dimension 2, zero accelerations), the six spheres
+stay static leaves.
 
-usage: python examples/example_pointmasses_dynamic.py [--steps 1000]
+Same entry points as the reference's examples/example_pointmasses_dynamic.py -- `set_planner_point(goal, n_obstacles=2,
+n_dyn_obstacles=0)`, `run_point_example(n_steps=1000, render=True)` -- over this build's batched arena
+(multi_robot_fabrics_amd.pointcell.PointRobotArena): one launch per control step for all robots of all scenes.  The remarks
+of the static example on rendering and on creeping contact apply.
+
+usage: python examples/example_pointmasses_dynamic.py [--steps 1000] [--scenes 1]
 """
 import argparse
 import json
 import os
 import sys
+import warnings
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-
-from multi_robot_fabrics_amd.goals import GoalComposition
-from multi_robot_fabrics_amd.kinematics import GenericURDFFk
-from multi_robot_fabrics_amd.planner import ParameterizedFabricPlanner
+from examples.example_pointmasses_static import GOALS, ROBOT_RADIUS, SPHERES, STARTS, URDF
+from multi_robot_fabrics_amd.goals import point_robot_goal
+from multi_robot_fabrics_amd.planner import point_planner
+from multi_robot_fabrics_amd.pointcell import PointRobotArena
 
 
 def set_planner_point(goal, n_obstacles: int = 2, n_dyn_obstacles=0):
-    """:101-130."""
-    degrees_of_freedom = 3
-    with open(os.path.join(ROOT, "examples", "simulation_environments", "urdfs", "pointRobot1.urdf"), "r") as file:
-        urdf = file.read()
-    fk = GenericURDFFk(urdf, "world", "base_link")
-    planner = ParameterizedFabricPlanner(
-        degrees_of_freedom, fk,
-        collision_geometry="-2.0 / (x ** 1) * xdot ** 2",
-        collision_finsler="1.0/(x**2) * (1 - ca.heaviside(xdot))* xdot**2")
-    planner.set_components(["base_link"], {}, goal=goal, number_obstacles=n_obstacles,
-                           number_dynamic_obstacles=n_dyn_obstacles, dynamic_obstacle_dimension=2)
-    planner.concretize()
-    return planner
+    """-> the point-robot planner with n_obstacles static and n_dyn_obstacles planar moving sphere leaves."""
+    return point_planner(URDF, goal, n_static=n_obstacles, n_dynamic=n_dyn_obstacles, dynamic_dimension=2)
 
 
-def run_point_example(n_steps=1000, render=True):
-    """The reference's signature (:133); there is no renderer in this build, `render` is ignored with a warning."""
+def run_point_example(n_steps=1000, render=True, *, scenes=1, start_jitter=0.0):
     if render:
-        import warnings
         warnings.warn("multi-robot-fabrics_amd has no renderer: render=True is ignored", RuntimeWarning, stacklevel=2)
-    obstacles_pos = [[1, 1.25, 0], [1, 3.75, 0], [1, -1.25, 0], [-1.1, 0, 0], [-1.1, 2.5, 0], [-1.1, -2.5, 0]]    # :145
-    obstacles_radius = [1, 1, 1, 1, 1, 1]
-    robots_pos = np.array([[-2.5, 0.01, 0.0], [-2.5, -2.49, 0.0], [2.5, 1.26, 0.0], [2.5, 3.74, 0.0]])             # :149
-    goal_robots = [np.array([1.5, 3.76]), np.array([1.5, 1.26]), np.array([-2.5, 0.01]), np.array([-2.5, -2.49])]
-    r_robots = [np.array(0.2)] * 4
-    n_robots = 4
-    goal = GoalComposition(name="goal", content_dict={
-        "subgoal0": {"weight": 1, "is_primary_goal": True, "indices": [0, 1], "parent_link": "world",
-                     "child_link": "base_link", "desired_position": [1.5, 0.99], "epsilon": 0.1, "type": "staticSubGoal"}})
-    planner_point = set_planner_point(goal, n_obstacles=len(obstacles_pos), n_dyn_obstacles=n_robots - 1)
-    q = robots_pos.copy()
-    qdot = np.zeros_like(q)
-    dt = 0.01
-    min_clear, first_contact = np.inf, None
-    pos_obs = [np.array(p, dtype=float) for p in obstacles_pos]
-    for step in range(n_steps):
-        action = np.zeros((n_robots, 3))
-        for i in range(n_robots):                                                                                  # :176-212
-            others = [j for j in range(n_robots) if j != i]
-            dyn = {}
-            for k, j in enumerate(others):
-                dyn["x_obst_dynamic_%d" % k] = q[j, 0:2]
-                dyn["xdot_obst_dynamic_%d" % k] = qdot[j, 0:2]
-                dyn["xddot_obst_dynamic_%d" % k] = np.array([0.0, 0.0])
-                dyn["radius_obst_dynamic_%d" % k] = r_robots[j]
-            action[i] = planner_point.compute_action(q=q[i], qdot=qdot[i], x_goal_0=goal_robots[i],
-                                                     weight_goal_0=goal.sub_goals()[0].weight(), x_obsts=pos_obs,
-                                                     radius_obsts=obstacles_radius, radius_body_base_link=r_robots[i], **dyn)
-        qdot = qdot + dt * action
-        q = q + dt * qdot
-        for i in range(n_robots):
-            for j in range(i + 1, n_robots):
-                min_clear = min(min_clear, float(np.linalg.norm(q[i, :2] - q[j, :2]) - 0.4))
-            for p, r in zip(obstacles_pos, obstacles_radius):
-                min_clear = min(min_clear, float(np.linalg.norm(q[i, :2] - np.array(p[:2])) - r - 0.2))
-        if first_contact is None and min_clear < 0.0:
-            first_contact = step
-    dist = [float(np.linalg.norm(q[i, :2] - goal_robots[i])) for i in range(n_robots)]
-    return {"steps": n_steps, "distance_to_goal_m": dist, "min_clearance_m": min_clear, "first_contact_step": first_contact,
-            "final_speed": [float(np.linalg.norm(v)) for v in qdot]}
+    goal = point_robot_goal()
+    planner = set_planner_point(goal, n_obstacles=len(SPHERES), n_dyn_obstacles=len(STARTS) - 1)
+    arena = PointRobotArena(planner, STARTS, GOALS, SPHERES, [1.0] * len(SPHERES), robot_radius=ROBOT_RADIUS,
+                            goal_weight=goal.sub_goals()[0].weight(), scenes=scenes, start_jitter=start_jitter)
+    return arena.run(n_steps)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=1000)
-    print(json.dumps(run_point_example(n_steps=ap.parse_args().steps, render=False), indent=1))
+    ap.add_argument("--scenes", type=int, default=1)
+    args = ap.parse_args()
+    print(json.dumps(run_point_example(n_steps=args.steps, render=False, scenes=args.scenes,
+                                       start_jitter=0.05 if args.scenes > 1 else 0.0), indent=1))

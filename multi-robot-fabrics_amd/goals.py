@@ -83,3 +83,10 @@ def panda_pick_place_goal(orientation_weight=10.0):
              type="staticJointSpaceSubGoal"),
     ]
     return GoalComposition(name="goal", content_dict={"subgoal%d" % k: part for k, part in enumerate(parts)})
+
+
+def point_robot_goal(position=(1.5, 0.99), weight=1.0):
+    """The single planar goal of the point-mass examples (a placeholder: every robot's own goal is a runtime parameter)."""
+    return GoalComposition(name="goal", content_dict={"subgoal0": dict(
+        weight=weight, is_primary_goal=True, indices=[0, 1], parent_link="world", child_link="base_link",
+        desired_position=list(position), epsilon=0.1, type="staticSubGoal")})

@@ -348,3 +348,17 @@ def panda_planner(urdf_path, mount, goal, link_numbers, n_static, n_dynamic, dt=
                            dynamic_obstacle_dimension=3, number_plane_constraints=1, limits=_config.PANDA_LIMITS)
     planner.concretize(mode="vel", time_step=dt)
     return planner
+
+
+def point_planner(urdf_path, goal, n_static, n_dynamic=0, dynamic_dimension=3, device=None, **strings):
+    """One concretized point-robot planner as the point-mass examples configure it: x-y-heading chain read from `urdf_path`,
+    collision leaves on `base_link`, acceleration output.  Leaf strings default to those examples' (config.POINT_STRINGS)."""
+    with open(urdf_path, "r") as f:
+        fk = GenericURDFFk(f.read(), "world", "base_link")
+    planner = ParameterizedFabricPlanner(3, fk, **dict(_config.POINT_STRINGS, **strings))
+    if device is not None:
+        planner.device = device
+    planner.set_components(collision_links=["base_link"], goal=goal, number_obstacles=int(n_static),
+                           number_dynamic_obstacles=int(n_dynamic), dynamic_obstacle_dimension=int(dynamic_dimension))
+    planner.concretize()
+    return planner

@@ -14,6 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 FILES = ["examples/example_pandas_Jointspace.py", "examples/example_pandas_cartesian.py",
+         "examples/example_pointmasses_static.py", "examples/example_pointmasses_dynamic.py",
          "examples/evaluation/evaluate_horizon.py", "examples/evaluation/evaluate_random_dynamic_scenarios.py"]
 LIMIT = 0.35
 

@@ -200,3 +200,45 @@ def test_random_pick_and_place_evaluation_on_device():
     res = run_case("rollouts dynamic", params, B=24, steps=3000, n_blocks=1, seed=3)
     assert res["all_finite"] and res["collision_episodes"] == 0
     assert res["success_rate"] >= 0.75, res          # the arms do pick their block and bring it home
+
+
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_point_arena_step_equals_one_compute_action_per_robot(dynamic):
+    """The arena's batched control step (one launch for all robots, the others gathered into every row's obstacle list on
+    the device) computes what the reference's loop computes with one planner.compute_action(**kwargs) per robot -- the
+    spheres static, the other robots static too or passed by the per-index dynamic keywords."""
+    import examples.example_pointmasses_dynamic as dyn_ex
+    import examples.example_pointmasses_static as sta_ex
+    from multi_robot_fabrics_amd.goals import point_robot_goal
+    from multi_robot_fabrics_amd.pointcell import PointRobotArena
+    goal = point_robot_goal()
+    R, K = len(sta_ex.STARTS), len(sta_ex.SPHERES)
+    planner = (dyn_ex.set_planner_point(goal, n_obstacles=K, n_dyn_obstacles=R - 1) if dynamic else
+               sta_ex.set_planner_point(goal, n_obstacles=K + R - 1))
+    arena = PointRobotArena(planner, sta_ex.STARTS, sta_ex.GOALS, sta_ex.SPHERES, [1.0] * K, robot_radius=sta_ex.ROBOT_RADIUS)
+    for _ in range(40):                                   # get the robots moving first
+        arena.step()
+    q, qd = arena.q.cpu().numpy().T.copy(), arena.qd.cpu().numpy().T.copy()
+    arena.step()
+    acc = (arena.qd.cpu().numpy().T - qd) / arena.dt
+    spheres = [np.array(s, dtype=float) for s in sta_ex.SPHERES]
+    for i in range(R):
+        others = [j for j in range(R) if j != i]
+        kw = dict(q=q[i], qdot=qd[i], x_goal_0=np.array(sta_ex.GOALS[i]), weight_goal_0=1.0, radius_body_base_link=np.array(0.2))
+        if dynamic:
+            kw.update(x_obsts=spheres, radius_obsts=[1.0] * K)
+            for k, j in enumerate(others):
+                kw.update({f"x_obst_dynamic_{k}": q[j, :2], f"xdot_obst_dynamic_{k}": qd[j, :2],
+                           f"xddot_obst_dynamic_{k}": np.zeros(2), f"radius_obst_dynamic_{k}": np.array(0.2)})
+        else:
+            kw.update(x_obsts=spheres + [np.array([q[j, 0], q[j, 1], 0.0]) for j in others], radius_obsts=[1.0] * K + [0.2] * (R - 1))
+        want = planner.compute_action(**kw)
+        assert np.allclose(acc[i], want, rtol=1e-9, atol=1e-9), (i, acc[i], want)
+
+
+def test_point_arena_many_scenes():
+    from examples.example_pointmasses_static import run_point_example
+    one = run_point_example(n_steps=50, render=False)
+    many = run_point_example(n_steps=50, render=False, scenes=7)
+    assert np.allclose(one["distance_to_goal_m"], many["distance_to_goal_m"], rtol=0, atol=1e-12)
+    assert len(many["all_scenes"]["min_clearance_m"]) == 7
