@@ -718,6 +718,8 @@ int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scen, const void* q0,
   const int64_t rows = n_scen * N;
   const int M = S * (N - 1);
   if (M == 0) return mrf_rollout_cartesian(h, rows, q0, qdot0, params, 0, 0, nullptr, nullptr, nullptr, nullptr, avg_out, traj_q, traj_qd, stream);
+  // small batches: one wave per scenario, the other robots' start states staged in LDS once (no obstacle arrays at all)
+  if (int rc = mrf_host::rollout_cartesian_coop(h, n_scen, q0, qdot0, params, avg_out, traj_q, traj_qd, stream); rc != 1) return rc;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
   if (cart_work_need(h, n_scen) > h->cart_work_bytes) {
@@ -849,7 +851,8 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
     if (rc && hr && ha->err.empty()) ha->err = hr->err;
     return rc;
   };
-  if (hr && hr->episode_rollout_kind == MRF_ROLLOUT_CARTESIAN && hr->cfg.n_robots > 1 && hr->cfg.n_spheres > 0) {
+  if (hr && hr->episode_rollout_kind == MRF_ROLLOUT_CARTESIAN && hr->cfg.n_robots > 1 && hr->cfg.n_spheres > 0 &&
+      !mrf_host::coop_applies(hr, n_scen)) {
     if (int rc = cart_work_ensure(hr, n_scen)) {  // outside any capture: the captured step must not allocate
       if (ha->err.empty()) ha->err = hr->err;
       return rc;

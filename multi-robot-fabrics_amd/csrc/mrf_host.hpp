@@ -150,6 +150,11 @@ int dispatch(mrf_handle* h, F f) {  // f(scalar tag, leaf-set tag)
 int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
                       void* qdot_io, const void* params, const void* sph_all, const int32_t* robot_slot, void* sumsq_io,
                       void* stream);
+// the cooperative (one wave per scenario) form of mrf_rollout_cartesian_coupled (mrf_kernels.hip); returns 1 when it does not
+// apply (batch above the crossover, kernel_select = 1, a single robot)
+bool coop_applies(const mrf_handle* h, int64_t n_scen);  // the batch-size / kernel_select rule of the coupled entry points
+int rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
+                           void* traj_q, void* traj_qd, void* stream);
 // frees h->comm (mrf_comm.hip); called by mrf_destroy
 void comm_release(mrf_handle* h);
 // frees h->staging (mrf_hostpath.hip); called by mrf_destroy

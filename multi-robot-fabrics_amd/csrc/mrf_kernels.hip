@@ -709,7 +709,10 @@ __host__ __device__ inline int coop_chunks(int n_robots) {
   return 5 * n_robots * 4 <= 64 ? 4 : (5 * n_robots * 2 <= 64 ? 2 : 1);
 }
 
-template <typename T, class LS, bool LO, bool COOP_ROLLOUT>
+// CART = true (with COOP_ROLLOUT) is the Cartesian rollout of mrf_rollout_cartesian_coupled in latency mode (FPC:421-458):
+// the obstacle table is the START state of the other robots -- staged once, every fold extrapolates x0 + k dt v, zero
+// accelerations -- and a step is action-then-integration.
+template <typename T, class LS, bool LO, bool COOP_ROLLOUT, bool CART = false>
 __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                     const T* __restrict__ q0, const T* __restrict__ qd0,
                                                     const T* __restrict__ prm, int use_accel, T* __restrict__ avg_out,
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   }
   __syncthreads();
   PrmView<T> P{prm_lds, N, i, {T(0), T(0), T(0)}, false};
-  if (COOP_ROLLOUT && ((cfg.goal_mask >> i) & 1)) {
+  if (COOP_ROLLOUT && !CART && ((cfg.goal_mask >> i) & 1)) {
     PandaKin<T> K0;
     panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K0);
 #pragma unroll
@@ -759,7 +762,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     P.own_goal = true;
   }
   const bool dyn = cfg.dynamic != 0;
-  const bool acc_on = dyn && (COOP_ROLLOUT || use_accel);
+  const bool acc_on = !CART && dyn && (COOP_ROLLOUT || use_accel);
   // The (other robot, sphere) pairs this lane folds are the same in every horizon step: their LDS offsets, radii and
   // multiplicities are worked out once (an integer division and a load from the constants per pair otherwise sit on
   // the single wave's critical path in every step).  Up to COOP_PRE pairs per lane; larger chunks use the loop.
@@ -784,7 +787,8 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
 #pragma unroll 1
   for (int k = 0; k < H; ++k) {
     MRF_STAMP(0);
-    if (COOP_ROLLOUT) {
+    const T tk = CART ? (T)k * cfg.dt : T(0);  // elapsed obstacle time of the Cartesian rollout
+    if (COOP_ROLLOUT && !CART) {
       T dq[7];
       bool small = true;
 #pragma unroll
@@ -812,6 +816,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
     PandaKin<T> K;
     panda_walk_own<T>(mount_own, R.cq, R.sq, R.qd, K);
     MRF_STAMP(2);
+    if (!CART || k == 0) {  // Cartesian rollout: the table holds the other robots' START states for the whole horizon
     __syncthreads();  // the previous step's readers are done with sph / xch
     if (LO) {
       if (writer) {
@@ -856,6 +861,7 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
           });
     }
     __syncthreads();
+    }
 
     MRF_STAMP(3);
     // ---- my ego point against my chunk of the other robots' spheres
@@ -874,6 +880,8 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
         if (pre_off[t] < 0) continue;
         const T* src = sph + pre_off[t];
         T x[3] = {src[0], src[1], src[2]}, v[3] = {src[3], src[4], src[5]}, a[3] = {src[6], src[7], src[8]};
+        if (CART)
+          for (int k3 = 0; k3 < 3; ++k3) x[k3] += tk * v[k3];
         accumulate_obstacle<typename LS::Collision>(cfg, E1, x, v, a, pre_rad[t], false, a1, pre_mul[t]);
       }
     } else if (cfg.n_ego > 0) {
@@ -886,6 +894,8 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
         if (jr >= N) jr -= N;
         const T* src = sph + ((size_t)jr * S + sp) * 9;
         T x[3] = {src[0], src[1], src[2]}, v[3] = {src[3], src[4], src[5]}, a[3] = {src[6], src[7], src[8]};
+        if (CART)
+          for (int k3 = 0; k3 < 3; ++k3) x[k3] += tk * v[k3];
         accumulate_obstacle<typename LS::Collision>(cfg, E1, x, v, a, cfg.sphere_r[LO ? lo_sphere(sp, m01, m45) : sp], false,
                                                     a1, LO ? T(lo_count(sp, m01, m45)) : T(1));
       }
@@ -931,12 +941,44 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
       panda_finish_row<LS, true>(cfg, R, P, K, E, acc, qdd, act);
     }
     MRF_STAMP(6);
-    if (COOP_ROLLOUT) {
+    if (COOP_ROLLOUT && CART) {  // system_step after the action (FPC:77-92,421-446)
+      T dq[7];
+      bool small = true;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (cfg.mode == MRF_MODE_VEL) {
+          R.qd[j] = act[j];
+          dq[j] = cfg.dt * R.qd[j];
+        } else {
+          dq[j] = cfg.dt * R.qd[j] + T(0.5) * cfg.dt * cfg.dt * act[j];
+          R.qd[j] += cfg.dt * act[j];
+        }
+        R.q[j] += dq[j];
+        small = small && (m_abs(dq[j]) < T(0.125));
+        sumsq += R.qd[j] * R.qd[j];
+      }
+      if (__all(small)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          T sd, cd;
+          small_sincos(dq[j], sd, cd);
+          const T cc = R.cq[j] * cd - R.sq[j] * sd;
+          const T ss = R.sq[j] * cd + R.cq[j] * sd;
+          R.cq[j] = cc;
+          R.sq[j] = ss;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+      }
+    } else if (COOP_ROLLOUT) {
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         R.qd[j] = act[j];
         sumsq += act[j] * act[j];
       }
+    }
+    if (COOP_ROLLOUT) {
       if (writer && traj_q) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) traj_q[((int64_t)k * 7 + j) * rows + row] = R.q[j];
@@ -1378,7 +1420,7 @@ bool use_coop(const mrf_handle* h, int64_t n_scen) {
   return n_scen <= h->coop_max_scen;
 }
 
-template <bool ROLLOUT>
+template <bool ROLLOUT, bool CART = false>
 int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, const void* prm, int use_accel, void* avg,
                 void* traj_q, void* traj_qd, void* qdd_out, void* act_out, hipStream_t st) {
   const bool lo = is_link_origin_table(h->cfg);
@@ -1388,7 +1430,7 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
     using LS = decltype(cl);
     const size_t lds = sizeof(T) * (21 * 64 + (size_t)h->cfg.n_robots * (S * 9 + MRF_NPARAM));
     dim3 block(64), grid((unsigned)n_scen);
-    auto k = lo ? mrf::k_coop_panda<T, LS, true, ROLLOUT> : mrf::k_coop_panda<T, LS, false, ROLLOUT>;
+    auto k = lo ? mrf::k_coop_panda<T, LS, true, ROLLOUT, CART> : mrf::k_coop_panda<T, LS, false, ROLLOUT, CART>;
     hipLaunchKernelGGL(k, grid, block, lds, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q, (const T*)qd,
                        (const T*)prm, use_accel, (T*)avg, (T*)traj_q, (T*)traj_qd, (T*)qdd_out, (T*)act_out);
     return check_hip(h, hipGetLastError(), "kernel launch");
@@ -1396,6 +1438,15 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
 }
 
 }  // namespace
+
+bool mrf_host::coop_applies(const mrf_handle* h, int64_t n_scen) { return use_coop(h, n_scen); }
+
+// mrf_rollout_cartesian_coupled in latency mode (one wave per scenario); 1 = the cooperative form does not apply here
+int mrf_host::rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
+                                     void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+  if (h->cfg.n_robots < 2 || h->cfg.n_spheres < 1 || !use_coop(h, n_scen)) return 1;
+  return launch_coop<true, true>(h, n_scen, q0, qdot0, params, 0, avg_out, traj_q, traj_qd, nullptr, nullptr, (hipStream_t)stream);
+}
 
 extern "C" {
 
