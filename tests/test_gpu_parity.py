@@ -376,10 +376,7 @@ def test_compute_action_coupled(oracle, n_per_link, use_accel, dynamic, kernel):
 
 def test_baseline_config_2_mrdf_two_pandas_ten_spheres(oracle):
     """BASELINE configs[1]: 2-Panda MRDF joint-space (no rollout), ~10 collision spheres per robot."""
-    cfg = config.panda_config(n_robots=2, horizon=1)
-    links, offs = config.sphere_offsets_per_link(2)          # 16 candidates; keep 10 spread over links 2..8
-    keep = [2, 3, 4, 6, 8, 9, 10, 12, 14, 15]
-    config.set_spheres(cfg, [links[i] for i in keep], [offs[i] for i in keep])
+    cfg = scenarios.baseline_config("C2")["cfg"]             # the configuration bench.py's `configs` block times
     batch = scenarios.panda_batch(cfg, 300, seed=81, x_min=0.15)
     sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
     ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, None)
@@ -394,12 +391,11 @@ def test_baseline_config_2_mrdf_two_pandas_ten_spheres(oracle):
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_baseline_config_5_eight_pandas_h50(oracle, kernel):
     """BASELINE configs[4] at its full shape: 8 Pandas, RF-CV, H=50, 20 spheres per robot (140 obstacle spheres each)."""
-    cfg = config.panda_config(n_robots=8, horizon=50)
+    cfg = scenarios.baseline_config("C5")["cfg"]            # the configuration bench.py's `configs` block times
     cfg.kernel_select = kernel
-    links, offs = config.c5_sphere_table()                  # 20 spheres, two of them on link 8 / the hand
+    links = list(cfg.sphere_link[:cfg.n_spheres])           # 20 spheres, two of them on link 8 / the hand
     assert len(links) == 20 and links.count(8) == 2 and all(links.count(l) >= 2 for l in range(1, 9))
-    config.set_spheres(cfg, links, offs)
-    cfg.goal_estimate_mask = 0xFE
+    assert cfg.goal_estimate_mask == 0xFE
     batch = scenarios.panda_batch(cfg, 10, seed=91, x_min=0.3, q_spread=0.15)
     want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
     h = FabricHandle(cfg, 0)
