@@ -340,6 +340,67 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     return out
 
 
+def robot_sharded_in_children(args, rank, world, guard_s):
+    """world > 1: the robot-sharded block runs in ONE CHILD PROCESS PER RANK with a process group of its own.  The
+    exchange it measures has its first contact with real links in the round-end run (RCCL with peers, IPC-mapped
+    buffers of another device): a hang there is ended by killing exactly that child after guard_s, and a GPU fault --
+    which aborts the faulting process, nothing a try/except in it could catch -- takes the child, not the rank that
+    holds the scenario-sharded headline.  Collective over the parents' group.  -> (block or None, clean); the block (rank
+    0) is the child's JSON, or an error marker naming what happened to which rank's child."""
+    import subprocess
+    import torch.distributed as dist
+    port = [None]
+    if rank == 0:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    # the launcher's agent store belongs to the parents' group: the children rendezvous on a port of their own
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--robot-shard-child", "--gpus", str(world), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--scenarios", str(args.scenarios), "--robots", str(args.robots),
+           "--horizon", str(args.horizon), "--dtype", args.dtype]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    # wait for this rank's child; a child that failed anywhere ends the others early (they would otherwise sit in a
+    # collective with a dead peer until the guard expires): the parents' store carries the flag
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:       # noqa: BLE001 -- no store to poll: every rank waits for its own guard
+        store = None
+    flag, what, deadline = "mrf_bench_shard_child_failed", None, time.monotonic() + guard_s
+    while proc.poll() is None:
+        if time.monotonic() > deadline:
+            what = f"timeout: no result within {guard_s:.0f} s"
+        elif store is not None and store.check([flag]):
+            what = "ended because another rank's child had failed"
+        if what:
+            proc.kill()             # this rank's own child, by its PID
+            break
+        time.sleep(0.2)
+    text = proc.communicate()[0] or ""
+    if what is None and proc.returncode != 0:
+        what = f"exit code {proc.returncode}" if proc.returncode > 0 else f"killed by signal {-proc.returncode}"
+    if what and store is not None:
+        store.set(flag, "1")
+    fates = [None] * world
+    dist.all_gather_object(fates, what)
+    clean = all(f is None for f in fates)
+    if rank != 0:
+        return None, clean
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    if clean and len(lines) == 1:
+        block = json.loads(lines[0])
+        block["isolation"] = "one child process per rank with its own process group (bench.robot_sharded_in_children)"
+        return block, True
+    if clean:
+        return {"error": f"the robot-sharded children printed {len(lines)} result lines instead of one"}, False
+    return {"error": "the robot-sharded block did not complete: " +
+                     "; ".join(f"rank {r}'s child: {f}" for r, f in enumerate(fates) if f is not None),
+            "children": fates}, False
+
+
 def run_guarded(fn, seconds, on_timeout):
     """fn() under a wall-clock watchdog thread: on_timeout() is called from the watchdog if fn has not returned after
     `seconds` (None: no guard).  on_timeout is expected to end the process."""
@@ -396,6 +457,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-robot-shard", action="store_true", help="skip the secondary robot-sharded block of the default run")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (C2, C3, C5, Cartesian rollout) of the --gpus 1 line")
+    ap.add_argument("--robot-shard-child", action="store_true", help=argparse.SUPPRESS)   # robot_sharded_in_children
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: libraries print banners there (RCCL's version block on communicator
@@ -446,6 +508,15 @@ def main():
     cfg_roll.goal_estimate_mask = ((1 << N) - 1) & ~1
     # main planner: n_obst_per_link = 1 as in the reference's evaluation scripts (evaluate_horizon.py:45)
     cfg_act = config.panda_config(n_robots=N, horizon=1, dynamic=1, scalar=scalar)
+    if args.robot_shard_child:      # one rank of the isolated robot-sharded block (robot_sharded_in_children)
+        if os.environ.get("MRF_BENCH_CHILD_FAULT") == str(rank):    # test hook: this rank dies the way a GPU fault kills it
+            os.abort()
+        args.scenarios = B
+        block = robot_sharded_block(cfg_roll, None, args, rank, world, local_rank)
+        if rank == 0:
+            emit(block)
+        run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: os._exit(SHARD_TIMEOUT_RC))
+        return
     batch = scenarios.panda_batch(cfg_roll, B, seed=1000 + rank)
     S = cfg_roll.n_spheres
 
@@ -581,22 +652,20 @@ def main():
         }
         out["parity_spot_check"] = parity_spot_check(cfg_roll, cfg_act, batch, avg, act)
 
-    # Secondary block: the robot-sharded transports.  Everything the headline line needs is in `out` by now, so a
-    # transport that hangs at world > 1 (first contact of RCCL / the peer exchange with more than one GPU) cannot take
-    # the scenario-sharded numbers with it: a per-rank wall-clock guard has rank 0 emit the line with an error marker
-    # and lets every rank leave through os._exit -- no re-exec, no collective, no GPU call on the way out.
+    # Secondary block: the robot-sharded transports.  Everything the headline line needs is in `out` by now, and at
+    # world > 1 the block runs in a child process per rank (robot_sharded_in_children): a transport that hangs or faults
+    # on its first contact with more than one GPU cannot take the scenario-sharded numbers with it.  Rank 0 then emits
+    # the line with an error marker and every rank leaves with SHARD_TIMEOUT_RC.
+    exit_code = 0
     if not args.no_robot_shard:
         args.scenarios = B
-
-        def expired():
-            if rank == 0:
-                out["robot_sharded"] = {"error": f"timeout: the robot-sharded block did not finish within {guard_s:.0f} s"}
-                emit(out)
-            os._exit(SHARD_TIMEOUT_RC)     # every rank: the run is NOT clean (spawn_ranks / the tests know this code)
-
-        guard_s = float(os.environ.get("MRF_BENCH_SHARD_TIMEOUT_S", "240"))
-        sharded_block = run_guarded(lambda: robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank),
-                                    guard_s if world > 1 else None, expired)
+        if world == 1:
+            sharded_block = robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank)
+        else:
+            guard_s = float(os.environ.get("MRF_BENCH_SHARD_TIMEOUT_S", "240"))
+            sharded_block, clean = robot_sharded_in_children(args, rank, world, guard_s)
+            if not clean:
+                exit_code = SHARD_TIMEOUT_RC     # every rank: the run is NOT clean (spawn_ranks / the tests know this code)
         if rank == 0:
             out["robot_sharded"] = sharded_block
     if rank == 0:
@@ -613,8 +682,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_roll, cfg_act, batch)
         emit(out)
-    if world > 1:   # the line is out: a peer that already left (guard above) must not keep this rank in the teardown
+    if world > 1:   # the line is out: a peer that has already left must not keep this rank in the teardown
         run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: os._exit(SHARD_TIMEOUT_RC))
+    if exit_code:
+        sys.stdout.flush()
+        os._exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -94,10 +94,10 @@ def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
 
 
 def test_stuck_secondary_block_cannot_take_the_headline_with_it():
-    """The wall-clock guard around the robot-sharded block (bench.py run_guarded): with a guard far shorter than the
-    block, rank 0 still emits the scenario-sharded headline -- with an error marker in place of the block -- and the run
-    ends with the distinct exit code bench.SHARD_TIMEOUT_RC (3): a hung exchange in processes that have touched the GPU
-    is not a clean run, but the line is there."""
+    """The wall-clock guard around the robot-sharded block (bench.robot_sharded_in_children: one child process per rank,
+    killed by its parent when the guard expires): with a guard far shorter than the block, rank 0 still emits the
+    scenario-sharded headline -- with an error marker in place of the block -- and the run ends with the distinct exit code
+    bench.SHARD_TIMEOUT_RC (3): a hung exchange is not a clean run, but the line is there."""
     env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_BENCH_SHARD_TIMEOUT_S="0.01")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
@@ -108,9 +108,31 @@ def test_stuck_secondary_block_cannot_take_the_headline_with_it():
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_spot_check"]["ok"]
-    # rank 0's own guard normally fires first; if the other rank's exit reaches it earlier, the block reports that instead
-    err = r["robot_sharded"].get("error") or r["robot_sharded"]["peer"]["error"]
-    assert err and ("timeout" in err or "Error" in err)
+    err = r["robot_sharded"]["error"]
+    assert "timeout" in err and "rank 0's child" in err, err
+
+
+def test_faulting_secondary_block_cannot_take_the_headline_with_it():
+    """A GPU fault aborts the process it happens in.  The robot-sharded block's first contact with real links must not be
+    able to do that to the ranks holding the headline: rank 1's CHILD dies by SIGABRT here (test hook), the parents
+    report whose child went how, end the other child early, emit the complete headline and leave with exit code 3."""
+    env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_BENCH_CHILD_FAULT="1",
+               MRF_PEER_TIMEOUT_MS="60000")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenarios", "2016"]
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    took = time.monotonic() - t0
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_spot_check"]["ok"] and "roofline" in r
+    assert "rank 1's child: killed by signal 6" in r["robot_sharded"]["error"], r["robot_sharded"]
+    assert r["robot_sharded"]["children"][1] == "killed by signal 6"
+    assert took < 200, took         # the surviving child was ended by the flag, not by the 240 s guard
 
 
 def test_four_ranks_one_gpu_one_robot_per_rank_plus_a_replica():
@@ -151,6 +173,7 @@ def test_eight_ranks_one_gpu_default_run_groups_3_3_2():
     assert abs(r["value"] - 8 * 504 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
     peer = r["robot_sharded"]["peer"]
     assert "error" not in peer, peer
+    assert "child process per rank" in r["robot_sharded"]["isolation"]
     assert peer["config"]["robot_groups"] == [3, 3, 2] and peer["config"]["scenarios_per_group"] == [504, 504, 252]
     assert peer["config"]["robots_per_rank_all"] == [1, 1, 1, 1, 1, 1, 2, 1]
     assert peer["parity_vs_fused_kernel"]["ok"], peer["parity_vs_fused_kernel"]
