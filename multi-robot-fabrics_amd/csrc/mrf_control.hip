@@ -68,13 +68,18 @@ __global__ __launch_bounds__(64) void k_publish_obstacles(const DevCfg<T>* __res
   if (!active) r = rows - 1;
   const int64_t scen = r / N;
   const int j = (int)(r - scen * N);
+  T qk[7];  // loads first, then the sincos calls (branches the compiler keeps loads behind): one round trip, not seven
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    qk[k] = q[k * rows + r];
+    xch[(3 * k + 2) * 64 + lane] = qd[k * rows + r];
+  }
 #pragma unroll
   for (int k = 0; k < 7; ++k) {
     T s, c;
-    m_sincos(q[k * rows + r], &s, &c);
+    m_sincos(qk[k], &s, &c);
     xch[(3 * k + 0) * 64 + lane] = c;
     xch[(3 * k + 1) * 64 + lane] = s;
-    xch[(3 * k + 2) * 64 + lane] = qd[k * rows + r];
   }
   __syncthreads();
   const bool dyn = cfg.dynamic != 0;

@@ -798,15 +798,27 @@ struct PandaState {
 };
 
 // ---------------------------------------------------------------------------- row state
+// all fourteen loads first: sincos has branches (argument reduction) the compiler does not move loads across, and a
+// load per joint in front of its sincos is seven dependent round trips to HBM at the start of every row
 template <typename T>
-__device__ __forceinline__ void load_state(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
-                                           PandaState<T>& R) {
+__device__ __forceinline__ void load_state_values(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
+                                                  PandaState<T>& R) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     R.q[j] = q[j * rows + r];
     R.qd[j] = qd[j * rows + r];
-    m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
   }
+}
+template <typename T>
+__device__ __forceinline__ void state_sincos(PandaState<T>& R) {
+#pragma unroll
+  for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+}
+template <typename T>
+__device__ __forceinline__ void load_state(int64_t rows, int64_t r, const T* __restrict__ q, const T* __restrict__ qd,
+                                           PandaState<T>& R) {
+  load_state_values(rows, r, q, qd, R);
+  state_sincos(R);
 }
 
 // Body radii of the links that share ego point g (0: link 3, 1: link 4, 2: links 5 and 6, 3: link 7, 4: link 8).

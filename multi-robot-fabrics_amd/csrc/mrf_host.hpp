@@ -13,6 +13,7 @@ struct mrf_handle {
   int device;
   uint64_t serial;        // process-wide creation counter: distinguishes a new handle that reuses a freed address
   int64_t coop_max_scen;  // batches up to this size use the cooperative kernels (auto mode)
+  int n_cus = 256;        // compute units of the device (persistent launches: four one-wave blocks per CU)
   void* dcfg;             // DevCfg<double> or DevCfg<float> on the device
   std::string err;
   // mrf_episode_run: cached HIP graph of one control step, the argument tuple it was captured for, and the stream

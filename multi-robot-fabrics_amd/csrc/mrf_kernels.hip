@@ -261,6 +261,10 @@ __global__ __launch_bounds__(256) MRF_ATTR_ACTION void k_action_panda(const DevC
   }
 }
 
+#ifdef MRF_OBST_RING  // experiment (tools/build_variant.sh ring - -DMRF_OBST_RING): obstacles prefetched by LDS-DMA, not shipped
+#include "experiments/obstacle_ring.hpp"
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
                                                         const T* __restrict__ q, const T* __restrict__ qd,
@@ -744,14 +748,15 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   const int64_t row = scen * N + i;
 
   PandaState<T> R;
-  load_state(rows, row, q0, qd0, R);
+  load_state_values(rows, row, q0, qd0, R);
   const T* mount_own = cfg.mount[i];
   // one scenario is a chain of dependent latencies: the 29 parameters per robot are fetched once into LDS instead of
-  // being re-read from global memory where they are used in every horizon step
+  // being re-read from global memory where they are used in every horizon step -- in the same round trip as the state
   for (int idx = lane; idx < MRF_NPARAM * N; idx += 64) {
     const int cpar = idx / N, rr = idx - cpar * N;
     prm_lds[idx] = prm[(int64_t)cpar * rows + scen * N + rr];
   }
+  state_sincos(R);
   __syncthreads();
   PrmView<T> P{prm_lds, N, i, {T(0), T(0), T(0)}, false};
   if (COOP_ROLLOUT && !CART && ((cfg.goal_mask >> i) & 1)) {
@@ -1144,13 +1149,18 @@ __global__ __launch_bounds__(64) void k_fk_spheres_panda(const DevCfg<T>* __rest
   int64_t r = (int64_t)blockIdx.x * 64 + lane;
   const bool active = r < rows;
   if (!active) r = rows - 1;
+  T qj[7];  // loads first, then the sincos calls (branches the compiler keeps loads behind): one round trip, not seven
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    qj[j] = q[j * rows + r];
+    xch[(3 * j + 2) * 64 + lane] = qd ? qd[j * rows + r] : T(0);
+  }
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     T s, c;
-    m_sincos(q[j * rows + r], &s, &c);
+    m_sincos(qj[j], &s, &c);
     xch[(3 * j + 0) * 64 + lane] = c;
     xch[(3 * j + 1) * 64 + lane] = s;
-    xch[(3 * j + 2) * 64 + lane] = qd ? qd[j * rows + r] : T(0);
   }
   __syncthreads();
   panda_walk_spheres<false, T>(
@@ -1187,16 +1197,20 @@ __global__ __launch_bounds__(64) void k_step_predict(const DevCfg<T>* __restrict
   if (!active) r = rows - 1;
   const int64_t scen = r / robot_count;
   const int lr = (int)(r - scen * robot_count);
+  T qn[7];  // loads first, then the sincos calls (branches the compiler keeps loads behind): one round trip, not seven
 #pragma unroll
   for (int j = 0; j < 7; ++j) {
     const T qdj = qd[j * rows + r];
-    const T qj = q_io[j * rows + r] + cfg.dt * qdj;
-    if (active) q_io[j * rows + r] = qj;
+    qn[j] = q_io[j * rows + r] + cfg.dt * qdj;
+    xch[(3 * j + 2) * 64 + lane] = qdj;
+  }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    if (active) q_io[j * rows + r] = qn[j];
     T s, c;
-    m_sincos(qj, &s, &c);
+    m_sincos(qn[j], &s, &c);
     xch[(3 * j + 0) * 64 + lane] = c;
     xch[(3 * j + 1) * 64 + lane] = s;
-    xch[(3 * j + 2) * 64 + lane] = qdj;
   }
   __syncthreads();
   const int m01 = cfg.lo_merge01, m45 = cfg.lo_merge45;
@@ -1563,6 +1577,7 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
   // per CU (1024 scenarios), 0.80 ms at 1.5 rounds, against a flat 0.49 ms of the row-per-lane kernel up to 8192
   // scenarios -> cooperative up to one round
   h->coop_max_scen = (int64_t)cus * 4;
+  h->n_cus = cus;
   return MRF_OK;
 }
 
@@ -1580,6 +1595,20 @@ void mrf_destroy(mrf_handle* h) {
 }
 
 const char* mrf_last_error(const mrf_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+#ifdef MRF_OBST_RING
+// ObstRing's preconditions: whole 16-byte pieces (aligned arrays), whole 64-row blocks, 32-bit obstacle strides; MRF_NO_RING=1 keeps the register-pipelined kernels (A/B, tools/prof_kernels.py)
+static bool ring_applies(const mrf_handle* h, int64_t elem, int64_t rows, int n_obst, const void* ox, const void* ov,
+                         const void* oa, const void* orad) {
+  static const bool off = [] {
+    const char* e = getenv("MRF_NO_RING");
+    return e && e[0] == '1';
+  }();
+  if (off || n_obst < 1 || h->cfg.n_ego <= 0) return false;
+  const uintptr_t bits = (uintptr_t)ox | (uintptr_t)ov | (uintptr_t)oa | (uintptr_t)orad;
+  return bits % 16 == 0 && rows % 64 == 0 && rows * 3 * elem < (int64_t)0xFFFFFFFFu;
+}
+#endif
 
 int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
                        int32_t n_obst, int32_t n_obst_static, const void* ox, const void* ov, const void* oa,
@@ -1606,6 +1635,16 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
                     (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
                     (const T*)orad, (T*)qddot_out, (T*)action_out);
     };
+#ifdef MRF_OBST_RING
+    // obstacles prefetched through the LDS ring when the arrays allow 16-byte DMA pieces (ObstRing)
+    if (ring_applies(h, (int64_t)sizeof(T), rows, n_obst, ox, ov, oa, orad)) {
+      const int64_t nb = rows / 64, resident = 4 * (int64_t)h->n_cus;  // persistent: one wave per SIMD
+      grid = dim3((unsigned)(nb < resident ? nb : resident));
+      block = dim3(64);
+      if (oa) return go(mrf::k_action_panda_ring<T, LS, true>);
+      return go(mrf::k_action_panda_ring<T, LS, false>);
+    }
+#endif
     // no obstacle accelerations (obst_a == NULL; the reference's drivers pass zeros, EXJ:411): 7 loads per obstacle
     if (oa) return go(mrf::k_action_panda<T, LS, true>);
     return go(mrf::k_action_panda<T, LS, false>);
