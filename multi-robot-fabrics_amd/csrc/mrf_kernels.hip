@@ -1003,6 +1003,10 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   if (COOP_ROLLOUT && writer) avg_out[row] = sumsq / (T)(H * 7);
 }
 
+#ifdef MRF_COOP4  // experiment (tools/build_variant.sh c4 - -DMRF_COOP4): four waves per scenario, measured slower, not shipped
+#include "experiments/coop4.hpp"
+#endif
+
 // ---------------------------------------------------------------------------- Cartesian rollout
 // RES: the first CART_RESIDENT<T> obstacles live in LDS for the whole rollout (one wave per block); RES = false is the
 // plain streaming form with 256-thread blocks (switch -DMRF_CART_STREAM_ONLY, A/B by tools/prof_kernels.py).
@@ -1406,6 +1410,9 @@ std::string validate(const mrf_config& c) {
   if (c.model == MRF_MODEL_PANDA7 && (c.n_goals < 0 || c.n_goals > 3)) return "panda n_goals must be 0..3";
   if (c.model == MRF_MODEL_PLANAR3 && (c.n_goals < 0 || c.n_goals > 1)) return "planar3 n_goals must be 0..1";
   if (c.obst_dim != 2 && c.obst_dim != 3) return "obst_dim must be 2 or 3";
+#ifdef MRF_COOP4
+  if (c.kernel_select == 3) return "";
+#endif
   if (c.kernel_select < 0 || c.kernel_select > 2) return "kernel_select must be 0 (auto), 1 (row-per-lane) or 2 (cooperative)";
   if (!(c.dt > 0) || !(c.eps > 0)) return "dt and eps must be positive";
   int prev = 0;
@@ -1430,9 +1437,42 @@ std::string validate(const mrf_config& c) {
 bool use_coop(const mrf_handle* h, int64_t n_scen) {
   if (5 * h->cfg.n_robots > 64) return false;
   if (h->cfg.kernel_select == 1) return false;
-  if (h->cfg.kernel_select == 2) return true;
+  if (h->cfg.kernel_select >= 2) return true;
   return n_scen <= h->coop_max_scen;
 }
+
+#ifdef MRF_COOP4
+// Four waves per scenario (k_coop4_panda, experiments/coop4.hpp): while the batch does not give every CU a scenario, a scenario
+// may as well have the CU's four SIMDs.  Joint-space rollout and coupled compute_action, up to six robots.
+// MRF_COOP4=0 keeps the one-wave form in auto mode (A/B).
+bool use_coop4(const mrf_handle* h, int64_t n_scen) {
+  static const bool off = [] {
+    const char* e = getenv("MRF_COOP4");
+    return e && e[0] == '0';
+  }();
+  if (h->cfg.n_robots > 6) return false;
+  if (h->cfg.kernel_select == 3) return true;
+  return h->cfg.kernel_select == 0 && !off && n_scen <= h->n_cus;
+}
+
+template <bool ROLLOUT>
+int launch_coop4(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, const void* prm, int use_accel, void* avg,
+                 void* traj_q, void* traj_qd, void* qdd_out, void* act_out, hipStream_t st) {
+  const bool lo = is_link_origin_table(h->cfg);
+  const int S = lo ? 8 : h->cfg.n_spheres;
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using LS = decltype(cl);
+    const size_t lds = sizeof(T) * mrf::coop4_lds_scalars(h->cfg.n_robots, S);
+    if (lds > 64 * 1024) return fail(h, MRF_E_CONFIG, "sphere table too large for the four-wave kernel");
+    dim3 block(256), grid((unsigned)n_scen);
+    auto k = lo ? mrf::k_coop4_panda<T, LS, true, ROLLOUT> : mrf::k_coop4_panda<T, LS, false, ROLLOUT>;
+    hipLaunchKernelGGL(k, grid, block, lds, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q, (const T*)qd,
+                       (const T*)prm, use_accel, (T*)avg, (T*)traj_q, (T*)traj_qd, (T*)qdd_out, (T*)act_out);
+    return check_hip(h, hipGetLastError(), "kernel launch");
+  });
+}
+#endif
 
 template <bool ROLLOUT, bool CART = false>
 int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, const void* prm, int use_accel, void* avg,
@@ -1659,6 +1699,10 @@ int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scen, const void* q, con
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q || !qdot || !params || !action_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
+#ifdef MRF_COOP4
+  if (use_coop4(h, n_scen))
+    return launch_coop4<false>(h, n_scen, q, qdot, params, (int)use_accel, nullptr, nullptr, nullptr, qddot_out, action_out, st);
+#endif
   if (use_coop(h, n_scen))
     return launch_coop<false>(h, n_scen, q, qdot, params, (int)use_accel, nullptr, nullptr, nullptr, qddot_out, action_out, st);
   const int spw = 64 / h->cfg.n_robots;
@@ -1684,6 +1728,10 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
+#ifdef MRF_COOP4
+  if (use_coop4(h, n_scen))
+    return launch_coop4<true>(h, n_scen, q0, qdot0, params, 1, avg_out, traj_q, traj_qd, nullptr, nullptr, st);
+#endif
   if (use_coop(h, n_scen))
     return launch_coop<true>(h, n_scen, q0, qdot0, params, 1, avg_out, traj_q, traj_qd, nullptr, nullptr, st);
   const int spw = 64 / h->cfg.n_robots;
