@@ -36,9 +36,9 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool ACC, typename T>
+template <bool ACC, typename T, int D_ = RING_DEPTH>
 struct ObstRing {
-  static constexpr int NV = ACC ? 10 : 7, G = RING_G<T, ACC>, SLOT = RING_SLOT<T, ACC>, D = RING_DEPTH;
+  static constexpr int NV = ACC ? 10 : 7, G = RING_G<T, ACC>, SLOT = RING_SLOT<T, ACC>, D = D_;
   T* ring;  // this wave's [D][G * CPI][64]
   int lane, n_obst;
   const char* src0[G];  // this lane's source of DMA g: obstacle 0 of the wave's first row block
@@ -51,8 +51,8 @@ struct ObstRing {
 
   __device__ __forceinline__ ObstRing(T* ring_, int lane_, int64_t rows, int64_t r0, int64_t rows_per_step, int64_t my_blocks,
                                       int n_obst_, const T* __restrict__ ox, const T* __restrict__ ov,
-                                      const T* __restrict__ oa, const T* __restrict__ orad)
-      : ring(ring_), lane(lane_), n_obst(n_obst_) {
+                                      const T* __restrict__ oa, const T* __restrict__ orad, int m_first = 0)
+      : ring(ring_), lane(lane_), n_obst(n_obst_) {  // obstacles [m_first, m_first + n_obst) of every row block
     const T* pv = ov ? ov : ox;  // missing arrays: any finite value, zeroed in the fold
     const T* pa = oa ? oa : ox;
     const int sub = lane / RING_LPC<T>;
@@ -63,8 +63,8 @@ struct ObstRing {
       if (ci >= NV) ci = NV - 1;  // padding component: the radius again
       const bool is_rad = ci == NV - 1;
       const T* b = ci < 3 ? ox + ci * rows : (ci < 6 ? pv + (ci - 3) * rows : (is_rad ? orad : pa + (ci - 6) * rows));
-      src0[g] = (const char*)(b + r0 + e);
       stride[g] = (unsigned)((is_rad ? rows : 3 * rows) * (int64_t)sizeof(T));
+      src0[g] = (const char*)(b + r0 + e) + (uint64_t)(unsigned)m_first * stride[g];
     }
     block_step = (uint64_t)rows_per_step * sizeof(T);
     total = my_blocks * n_obst;
@@ -90,7 +90,7 @@ struct ObstRing {
   }
   // the oldest unread item has landed when no more than the DMAs of the items issued after it are outstanding
   __device__ __forceinline__ void wait_oldest() const {
-    static_assert(D == 8, "wait_oldest spells out D - 1 = 7 counted waits");
+    static_assert(D <= 8, "wait_oldest spells out up to 7 counted waits");
     switch ((int)(issued - consumed - 1)) {
       case 0: wait_vm<0>(); break;
       case 1: wait_vm<G>(); break;
@@ -101,6 +101,20 @@ struct ObstRing {
       case 6: wait_vm<6 * G>(); break;
       default: wait_vm<7 * G>(); break;
     }
+  }
+  // the oldest item: wait for it and read it; release() afterwards frees its slot for the next DMA
+  __device__ __forceinline__ void take(T (&buf)[NV]) {
+    typedef const __attribute__((address_space(3))) T* lds_ptr;
+    wait_oldest();
+    lds_ptr src = (lds_ptr)(ring + slot_read * SLOT + lane);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) buf[c] = src[c * 64];
+  }
+  __device__ __forceinline__ void release() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be overwritten
+    ++consumed;
+    slot_read = slot_read + 1 == D ? 0 : slot_read + 1;
+    if (issued < total) issue_next();
   }
   // the n_obst obstacles of the current row block: fold(m, buf), m = 0 .. n_obst - 1
   template <class Fold>
@@ -141,6 +155,65 @@ __device__ __forceinline__ void obstacles_from_ring(const DevCfg<T>& cfg, ObstRi
     }
     accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
   });
+}
+
+// Cartesian rollout (measured, not wired in: profiles/r04_experiments.json "k_rollout_cart_panda obstacle ring"; the call
+// site was k_rollout_cart_panda's RES branch with a 3-slot ring beside a 7-obstacle resident tile, ring constructed with
+// my_blocks = horizon, rows_per_step = 0, m_first = nres): identical rollouts, 4.06 ms against 3.69 ms.
+// The first nres obstacles of a row are resident in LDS, the others come round again in every step --
+// through the ring, which keeps filling while the step is finished and the next chain is walked.  Resident and streamed
+// obstacles are folded alternately so that the ring is drained at an even pace.
+template <class CL, bool ACC, typename T, int D>
+__device__ __forceinline__ void obstacles_cart_ring(const DevCfg<T>& cfg, const T* __restrict__ res, int lane, int nres,
+                                                    ObstRing<ACC, T, D>& ring, int n_static, bool any_v, bool any_a, T tk,
+                                                    const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  constexpr int NV = ACC ? 10 : 7;
+  auto fold = [&](int m, T (&buf)[NV]) {
+    const bool is_static = m < n_static;
+    const bool has_v = any_v && !is_static, has_a = ACC && any_a && !is_static;
+    T xo[3], vo[3], ao[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      vo[c] = has_v ? buf[3 + c] : T(0);
+      xo[c] = buf[c] + tk * vo[c];  // x += dt*v per step (FPC:448-453)
+      if constexpr (ACC)
+        ao[c] = has_a ? buf[6 + c] : T(0);
+      else
+        ao[c] = T(0);
+    }
+    accumulate_obstacle<CL>(cfg, E, xo, vo, ao, buf[NV - 1], false, acc);
+  };
+  const int ns = ring.n_obst;
+  int jr = 0, js = 0;
+#pragma unroll 1
+  while (jr < nres && js < ns) {  // pairs: one resident, one streamed
+    T A[NV], B[NV];
+    lds_ptr src = (lds_ptr)(res + jr * (NV * 64) + lane);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) A[c] = src[c * 64];
+    ring.take(B);
+    fold(jr, A);
+    ring.release();
+    fold(nres + js, B);
+    ++jr;
+    ++js;
+  }
+#pragma unroll 1
+  for (; jr < nres; ++jr) {
+    T A[NV];
+    lds_ptr src = (lds_ptr)(res + jr * (NV * 64) + lane);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) A[c] = src[c * 64];
+    fold(jr, A);
+  }
+#pragma unroll 1
+  for (; js < ns; ++js) {
+    T B[NV];
+    ring.take(B);
+    ring.release();
+    fold(nres + js, B);
+  }
 }
 
 // compute_action with the obstacle ring: persistent one-wave blocks (four per CU), block b takes the 64-row blocks
