@@ -218,7 +218,7 @@ def _traffic_entry(prefix):
 
 def config_sizes(name, cus):
     """Scenarios per launch of a `configs` entry: C2 as SURVEY 8d names it, the others two full rounds of resident waves."""
-    n = {"C2": 2, "C3": 2, "C5": 8, "CART": 3}[name]
+    n = {"C2": 2, "C3": 2, "C5": 8, "CART": 3, "CARTC": 3}[name]
     return 65536 if name == "C2" else 2 * cus * 4 * (64 // n)
 
 
@@ -247,6 +247,10 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
         launch = lambda: h.rollout(q, qd, prm)
         units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_panda"
         bytes_unit = algorithmic_bytes_per_rollout_step(N, S, H, sb)
+    elif kind == "rollout_cartesian_coupled":
+        launch = lambda: h.rollout_cartesian_coupled(q, qd, prm)
+        units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_cartc_panda"
+        bytes_unit = sb * (28 + 7 * M) + sb * 23 / H                              # what the obstacle-array formulation would move
     else:
         sx, sv, _ = h.fk_spheres(q, qd)
         ox, ov, _, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv, None)

@@ -420,9 +420,11 @@ int mrf_episode_set_pick_place(mrf_handle* h_action, const mrf_state_machine_con
  * the obstacles compute_x_obsts_dyn_0 hands it (utils_fabrics_kinematics.py:3-33, EXC:330-352): the configured spheres
  * (cfg.sphere_link / _offset / _radius) of all other robots of the scenario at their current positions, moving with
  * their current velocities J qdot (zero when cfg.dynamic == 0) for the whole horizon, zero accelerations (FPC:33).
- * rows = n_scenarios * n_robots as in mrf_rollout; the obstacle arrays live in a work buffer owned by the handle
- * (allocated on the first call of a batch size; not inside a stream capture).  avg_vel_out [rows];
- * traj_q / traj_qd [H][7][rows] or NULL. */
+ * rows = n_scenarios * n_robots as in mrf_rollout.  Three forms, chosen by table and batch size: small batches run one
+ * wave per scenario; tables of up to 8 spheres per robot (or the link-origin table) in mode 'vel' keep the other robots'
+ * start states in an LDS tile for the whole horizon and touch no obstacle array at all; anything else assembles obstacle
+ * arrays in a work buffer owned by the handle (allocated on the first call of a batch size; not inside a stream capture)
+ * and runs mrf_rollout_cartesian on them.  avg_vel_out [rows]; traj_q / traj_qd [H][7][rows] or NULL. */
 int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* qdot0, const void* params,
                                   void* avg_vel_out, void* traj_q, void* traj_qd, void* stream);
 

@@ -725,6 +725,8 @@ int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scen, const void* q0,
   if (M == 0) return mrf_rollout_cartesian(h, rows, q0, qdot0, params, 0, 0, nullptr, nullptr, nullptr, nullptr, avg_out, traj_q, traj_qd, stream);
   // small batches: one wave per scenario, the other robots' start states staged in LDS once (no obstacle arrays at all)
   if (int rc = mrf_host::rollout_cartesian_coop(h, n_scen, q0, qdot0, params, avg_out, traj_q, traj_qd, stream); rc != 1) return rc;
+  // link-origin sphere table: the start states stay in an LDS tile for the whole horizon (no obstacle arrays either)
+  if (int rc = mrf_host::rollout_cartesian_tile(h, n_scen, q0, qdot0, params, avg_out, traj_q, traj_qd, stream); rc != 1) return rc;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
   if (cart_work_need(h, n_scen) > h->cart_work_bytes) {

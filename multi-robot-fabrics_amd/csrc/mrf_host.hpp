@@ -156,6 +156,8 @@ int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_
 bool coop_applies(const mrf_handle* h, int64_t n_scen);  // the batch-size / kernel_select rule of the coupled entry points
 int rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
                            void* traj_q, void* traj_qd, void* stream);
+int rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
+                           void* traj_q, void* traj_qd, void* stream);
 // frees h->comm (mrf_comm.hip); called by mrf_destroy
 void comm_release(mrf_handle* h);
 // frees h->staging (mrf_hostpath.hip); called by mrf_destroy

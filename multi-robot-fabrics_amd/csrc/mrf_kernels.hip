@@ -619,6 +619,190 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
   }
 }
 
+// Fold for the coupled Cartesian rollout: the tile holds the other robots' spheres as they are at the START of the horizon
+// (x0 in rows s*9 + 0..2, v in rows s*9 + 3..5); a sphere is folded at x0 + tk v with zero acceleration (FPC:33,448-453) --
+// the acceleration rows are not read (the generic publish parks the joint state there), the n.a_o terms compile out.
+// nsp distinct spheres per robot; radius and multiplicity per slot follow the tile (TILE_RADII / TILE_MULT).
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_from_tile_drift(const DevCfg<T>& cfg, const T* __restrict__ tile, int ls, int li, int N,
+                                                          int nsp, T tk, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  const int M = (N - 1) * nsp;
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  typedef const volatile __attribute__((address_space(3))) T* lds_vptr;
+  auto address = [&](int d, int sp) {
+    int jr = li + 1 + d;
+    if (jr >= N) jr -= N;
+    return (sp * 9) * 64 + ls * N + jr;
+  };
+  T bufA[8], bufB[8];  // x0[3], v[3], radius, multiplicity: ping-pong, the loop is unrolled by two
+  {
+    lds_vptr src = (lds_vptr)(tile + address(0, 0));  // volatile: keeps the first fetch out of the loop (obstacles_from_tile)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bufA[k] = src[k * 64];
+    bufA[6] = ((lds_vptr)tile)[TILE_RADII];
+    bufA[7] = ((lds_vptr)tile)[TILE_MULT];
+  }
+  if constexpr (!CL::generic) asm volatile("" ::"s"(cfg.jsign), "s"(cfg.cf.k), "s"(cfg.cg.k));
+  int dn = 0, sn = 0;  // (other robot, slot) of the sphere fetched last
+  auto fetch_next = [&](T (&buf)[8], bool advance) {
+    if (advance) {
+      if (++sn == nsp) {
+        sn = 0;
+        ++dn;
+      }
+    }
+    lds_ptr src = (lds_ptr)(tile + address(dn, sn));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) buf[k] = src[k * 64];
+    buf[6] = ((lds_ptr)tile)[TILE_RADII + sn];
+    buf[7] = ((lds_ptr)tile)[TILE_MULT + sn];
+  };
+  auto fold = [&](T (&buf)[8]) {
+    T x[3] = {buf[0] + tk * buf[3], buf[1] + tk * buf[4], buf[2] + tk * buf[5]};
+    const T zero[3] = {T(0), T(0), T(0)};
+    accumulate_obstacle<CL>(cfg, E, x, buf + 3, zero, buf[6], false, acc, buf[7]);
+  };
+  int m = 0;
+#pragma unroll 1
+  for (; m + 1 < M; m += 2) {
+    fetch_next(bufB, true);
+    fold(bufA);
+    fetch_next(bufA, m + 2 < M);  // past the end: re-reads the last sphere, never used
+    fold(bufB);
+  }
+  if (m < M) fold(bufA);  // odd count
+}
+
+// ---------------------------------------------------------------------------- coupled Cartesian rollout (up to 8 spheres per robot)
+// mrf_rollout_cartesian_coupled at throughput batch sizes: every robot rolls out its OWN fabric against the other robots'
+// spheres as they are at the START of the horizon, moving on at constant velocity (FPC:421-458, EXC:335-357).  Those spheres
+// belong to the robots of the same scenario, i.e. to neighbouring lanes: each lane walks its chain once, leaves its spheres
+// (x0, v) in the [72][64] tile of the joint-space kernel -- LO: the eight link origins, coincident ones merged; otherwise any
+// table of up to eight spheres, one per link with its offset being the evaluation scripts' (evaluate_horizon.py:45) -- and for
+// the whole horizon every fold reads the tile at x0 + k dt v.  No obstacle arrays in HBM (k_publish_obstacles + k_rollout_cart_panda stream 16 obstacles x 7
+// scalars per row and step), no per-step exchange either.  A step is action, then system_step (FPC:77-92); mode 'vel' (the
+// Panda drivers' mode, parameters_manipulators.py:12) -- 'acc' stays with the obstacle-array kernel.
+template <typename T, class LS, bool LO>
+__global__ __launch_bounds__(64) void k_rollout_cartc_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
+                                                             const T* __restrict__ q0, const T* __restrict__ qd0,
+                                                             const T* __restrict__ prm, T* __restrict__ avg_out,
+                                                             T* __restrict__ traj_q, T* __restrict__ traj_qd) {
+  __shared__ T xch[TILE_SCALARS];
+  const DevCfg<T>& cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int nsp = LO ? 8 - cfg.lo_merge01 - cfg.lo_merge45 : cfg.n_spheres;  // distinct spheres per robot
+  if constexpr (LO) {
+    stage_sphere_radii(cfg, xch, lane);  // visible after the publish barrier
+  } else if (lane < nsp) {
+    xch[TILE_RADII + lane] = cfg.sphere_r[lane];
+    xch[TILE_MULT + lane] = T(1);
+  }
+  const int N = cfg.n_robots;
+  const int spw = 64 / N;  // scenarios per wave
+  int ls = lane / N;
+  const int li = lane - ls * N;
+  int64_t scen = (int64_t)blockIdx.x * spw + ls;
+  const bool active = ls < spw && scen < n_scen;
+  if (ls >= spw) ls = 0;  // idle tail lanes shadow the wave's first scenario (no stores)
+  if (scen >= n_scen || !active) scen = (int64_t)blockIdx.x * spw + ls;
+  if (scen >= n_scen) scen = n_scen - 1;
+  const int64_t rows = n_scen * N;
+  const int64_t row = scen * N + li;
+
+  PandaState<T> R;
+  load_state(rows, row, q0, qd0, R);
+  const T* mount_own = cfg.mount[li];
+  PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
+  if constexpr (!LO) {
+    // Any table: the rolled sphere walk reads the joint state by joint index, so cos q, sin q, qdot are parked in the
+    // tile's acceleration rows (j*9 + 6..8, which the Cartesian fold never reads) and the spheres go to the x / v rows.
+    // Own lane's entries only until the barrier.
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      xch[(j * 9 + 6) * 64 + lane] = R.cq[j];
+      xch[(j * 9 + 7) * 64 + lane] = R.sq[j];
+      xch[(j * 9 + 8) * 64 + lane] = R.qd[j];
+    }
+    const bool dyn = cfg.dynamic != 0;
+    panda_walk_spheres<false, T>(
+        cfg, mount_own,
+        [&](int j, T& c, T& sn, T& qdj) {
+          c = xch[(j * 9 + 6) * 64 + lane];
+          sn = xch[(j * 9 + 7) * 64 + lane];
+          qdj = xch[(j * 9 + 8) * 64 + lane];
+        },
+        [&](int sp, const T* x, const T* v, const T*) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            xch[(sp * 9 + c) * 64 + lane] = x[c];
+            xch[(sp * 9 + 3 + c) * 64 + lane] = dyn ? v[c] : T(0);
+          }
+        });
+    __syncthreads();
+  }
+  T sumsq = T(0);
+  const int H = cfg.horizon;
+  // system_step 'vel' (FPC:77-92): qdot = action, q += dt*qdot; cos q / sin q advance by the angle-sum formula while every
+  // |dq| of the wave is small.  Written at the TOP of the following iteration (and once after the last one), where neither
+  // the action nor the solve's temporaries are live -- the order the joint-space kernel keeps its registers with.
+  auto system_step = [&](int k_done) {
+    T dq[7];
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      dq[j] = cfg.dt * R.qd[j];
+      small = small && (m_abs(dq[j]) < T(0.125));
+      R.q[j] += dq[j];
+    }
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T sd, cd;
+        small_sincos(dq[j], sd, cd);
+        const T c = R.cq[j] * cd - R.sq[j] * sd;
+        const T sn = R.sq[j] * cd + R.cq[j] * sd;
+        R.cq[j] = c;
+        R.sq[j] = sn;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    }
+    if (active && traj_q) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) traj_q[((int64_t)k_done * 7 + j) * rows + row] = R.q[j];
+    }
+    if (active && traj_qd) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) traj_qd[((int64_t)k_done * 7 + j) * rows + row] = R.qd[j];
+    }
+  };
+#pragma unroll 1
+  for (int k = 0; k < H; ++k) {
+    if (k > 0) system_step(k - 1);
+    const T tk = to_uniform((T)k * cfg.dt);  // elapsed obstacle time
+    T qdd[7], act[7];
+    panda_solve_row<LS, kSingleWalk<LS>>(
+        cfg, mount_own, R, P,
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+          obstacles_from_tile_drift<typename LS::Collision>(cfg, xch, ls, li, N, nsp, tk, E, acc);
+        },
+        qdd, act,
+        [&](const PandaKin<T>& K1) {
+          if (!LO || k != 0) return;  // the tile holds the start states for the whole horizon
+          publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, false, cfg.jsign, cfg.lo_merge01, cfg.lo_merge45);
+          __syncthreads();
+        });
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      R.qd[j] = act[j];
+      sumsq += act[j] * act[j];
+    }
+  }
+  if (H > 0) system_step(H - 1);
+  if (active) avg_out[row] = sumsq / (T)(H * 7);
+}
+
 // ---------------------------------------------------------------------------- coupled compute_action
 // One control step's compute_action for every robot of every scenario with the host-side obstacle assembly of the
 // reference's loop (EXJ:394-412) done on chip: the dynamic obstacles of robot i are the configured spheres of all
@@ -1494,6 +1678,30 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
 }  // namespace
 
 bool mrf_host::coop_applies(const mrf_handle* h, int64_t n_scen) { return use_coop(h, n_scen); }
+
+// mrf_rollout_cartesian_coupled with the other robots' start states in the LDS tile (the link-origin table, or any table of
+// up to eight spheres per robot; mode 'vel'); 1 = this form does not apply here.  MRF_CART_TILE=0 keeps the obstacle-array
+// path (A/B).
+int mrf_host::rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
+                                     void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+  static const bool off = [] {
+    const char* e = getenv("MRF_CART_TILE");
+    return e && e[0] == '0';
+  }();
+  const bool lo = is_link_origin_table(h->cfg);
+  if (off || h->cfg.n_robots < 2 || h->cfg.n_robots > 64 || h->cfg.mode != MRF_MODE_VEL || h->cfg.n_spheres < 1 ||
+      (!lo && h->cfg.n_spheres > 8))
+    return 1;
+  const int spw = 64 / h->cfg.n_robots;
+  dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using LS = decltype(cl);
+    auto k = lo ? mrf::k_rollout_cartc_panda<T, LS, true> : mrf::k_rollout_cartc_panda<T, LS, false>;
+    return launch(h, k, grid, block, (hipStream_t)stream, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0, (const T*)qdot0,
+                  (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+  });
+}
 
 // mrf_rollout_cartesian_coupled in latency mode (one wave per scenario); 1 = the cooperative form does not apply here
 int mrf_host::rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,

@@ -170,7 +170,7 @@ def other_robot_obstacles(cfg, batch, spheres_x, spheres_v=None, spheres_a=None)
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE.json configs
-BASELINE_CONFIGS = ("C2", "C3", "C5", "CART")
+BASELINE_CONFIGS = ("C2", "C3", "C5", "CART", "CARTC")
 
 
 def baseline_config(name, scalar=abi.F64):
@@ -181,6 +181,8 @@ def baseline_config(name, scalar=abi.F64):
         C5    8-Panda RF-CV H=50, 20 spheres per robot (config.c5_sphere_table, 140 obstacle spheres per robot) -> mrf_rollout
         CART  3-Panda Cartesian rollout H=30, M=16 constant-velocity obstacle spheres per robot (the other
               robots' link origins at the start state), no obstacle accelerations (FPC:33) -> mrf_rollout_cartesian
+        CARTC the same rollout through mrf_rollout_cartesian_coupled, the call the Cartesian example driver makes (EXC:330-399):
+              the other robots' start states never leave the chip (LDS tile, k_rollout_cartc_panda)
     -> dict(cfg, kind, batch = keyword arguments of panda_batch, scenarios_per_cu_round, label)."""
     if name == "C2":
         cfg = _config.panda_config(n_robots=2, horizon=1, scalar=scalar)
@@ -200,6 +202,10 @@ def baseline_config(name, scalar=abi.F64):
     if name == "CART":
         cfg = _config.panda_config(n_robots=3, horizon=30, scalar=scalar)
         return dict(cfg=cfg, kind="rollout_cartesian", batch=dict(x_min=0.1), label="3-Panda Cartesian rollout H=30, M=16")
+    if name == "CARTC":
+        cfg = _config.panda_config(n_robots=3, horizon=30, scalar=scalar)
+        return dict(cfg=cfg, kind="rollout_cartesian_coupled", batch=dict(x_min=0.1),
+                    label="3-Panda Cartesian rollout H=30 against the other robots' spheres (coupled entry point)")
     raise KeyError(f"unknown baseline configuration {name!r}: {BASELINE_CONFIGS}")
 
 

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-@pytest.mark.parametrize("name", ["C2", "C3", "C5", "CART"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C5", "CART", "CARTC"])
 def test_config_entry(name):
     import bench
     from multi_robot_fabrics_amd import scenarios

@@ -222,14 +222,15 @@ def test_rollout_cartesian_more_obstacles_than_resident(oracle, accel):
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("n_robots,per_link,dynamic", [(2, 1, 1), (3, 2, 1), (2, 4, 1), (3, 1, 0), (1, 1, 1)])
+@pytest.mark.parametrize("n_robots,per_link,dynamic", [(2, 1, 1), (3, 2, 1), (2, 4, 1), (3, 1, 0), (1, 1, 1), (3, 1, 1), (4, 1, 1)])
 def test_rollout_cartesian_coupled(oracle, n_robots, per_link, dynamic, kernel):
     """mrf_rollout_cartesian_coupled (EXC:330-399 on the device): every robot's Cartesian rollout against the configured
     spheres of the other robots of its scenario -- the simulator's table with per_link spheres per link, positions and
     velocities at the start state, zero accelerations -- equals the oracle's rollout_cartesian fed with the host-side
-    assembly of those obstacles (static fabrics: zero obstacle velocities; one robot: no obstacles).  kernel 1: obstacle
-    arrays assembled on the device + the row-per-lane rollout kernel; kernel 2: one wave per scenario, the other robots'
-    start states staged in LDS (k_coop_panda in its Cartesian mode)."""
+    assembly of those obstacles (static fabrics: zero obstacle velocities; one robot: no obstacles).  kernel 1, one sphere per
+    link (the link-origin table): the other robots' start states in the LDS tile for the whole horizon
+    (k_rollout_cartc_panda); kernel 1, other tables: obstacle arrays assembled on the device + the row-per-lane rollout
+    kernel; kernel 2: one wave per scenario, the start states staged in LDS (k_coop_panda in its Cartesian mode)."""
     cfg = config.panda_config(n_robots=n_robots, horizon=5, dynamic=dynamic)
     cfg.kernel_select = kernel
     links, offs = config.sphere_offsets_per_link(per_link)

@@ -21,4 +21,5 @@ python3 $root/tools/make_traffic.py $pmc config_C2_${dt}_B65536 --horizon 1 --ke
 python3 $root/tools/make_traffic.py $pmc config_C3_${dt}_B$((2*cus*4*32)) --horizon 20 --kernel-substring "k_rollout_panda<double, LS_reference, true>" --out $tj >> $out/summary.log 2>&1
 python3 $root/tools/make_traffic.py $pmc config_C5_${dt}_B$((2*cus*4*8)) --horizon 50 --kernel-substring "k_rollout_panda<double, LS_reference, false>" --out $tj >> $out/summary.log 2>&1
 python3 $root/tools/make_traffic.py $pmc config_CART_${dt}_B$((2*cus*4*21)) --horizon 30 --kernel-substring "k_rollout_cart_panda<" --out $tj >> $out/summary.log 2>&1
+python3 $root/tools/make_traffic.py $pmc config_CARTC_${dt}_B$((2*cus*4*21)) --horizon 30 --kernel-substring "k_rollout_cartc_panda<" --out $tj >> $out/summary.log 2>&1
 tail -c 2500 $out/summary.log; cat $out/prof_configs.txt | cut -c1-400

@@ -2,7 +2,7 @@
 """The BASELINE.json configurations beside the bench headline -- C2, C3, C5 and the Cartesian rollout, built by
 scenarios.baseline_config and launched by bench.run_config exactly as bench.py's `configs` block launches them -- for
 rocprofv3 passes (tools/collect_config_pmc.sh) and for a quick look at their kernel times.
-usage: python3 tools/prof_configs.py [f64|f32] [C2 C3 C5 CART ...] [--check]"""
+usage: python3 tools/prof_configs.py [f64|f32] [C2 C3 C5 CART CARTC ...] [--check]"""
 import json
 import os
 import sys
