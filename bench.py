@@ -344,13 +344,14 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     return out
 
 
-def robot_sharded_in_children(args, rank, world, guard_s):
+def robot_sharded_in_children(args, rank, world, guard_s, child_cmd=None):
     """world > 1: the robot-sharded block runs in ONE CHILD PROCESS PER RANK with a process group of its own.  The
     exchange it measures has its first contact with real links in the round-end run (RCCL with peers, IPC-mapped
     buffers of another device): a hang there is ended by killing exactly that child after guard_s, and a GPU fault --
     which aborts the faulting process, nothing a try/except in it could catch -- takes the child, not the rank that
     holds the scenario-sharded headline.  Collective over the parents' group.  -> (block or None, clean); the block (rank
-    0) is the child's JSON, or an error marker naming what happened to which rank's child."""
+    0) is the child's JSON, or an error marker naming what happened to which rank's child.  child_cmd: the command to run
+    instead of this file in its child mode (tests/test_bench_children.py drives the protocol on CPU with stand-ins)."""
     import subprocess
     import torch.distributed as dist
     port = [None]
@@ -363,9 +364,9 @@ def robot_sharded_in_children(args, rank, world, guard_s):
     # the launcher's agent store belongs to the parents' group: the children rendezvous on a port of their own
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, os.path.abspath(__file__), "--robot-shard-child", "--gpus", str(world), "--steps", str(args.steps),
-           "--warmup", str(args.warmup), "--scenarios", str(args.scenarios), "--robots", str(args.robots),
-           "--horizon", str(args.horizon), "--dtype", args.dtype]
+    cmd = child_cmd or [sys.executable, os.path.abspath(__file__), "--robot-shard-child", "--gpus", str(world),
+                        "--steps", str(args.steps), "--warmup", str(args.warmup), "--scenarios", str(args.scenarios),
+                        "--robots", str(args.robots), "--horizon", str(args.horizon), "--dtype", args.dtype]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
     # wait for this rank's child; a child that failed anywhere ends the others early (they would otherwise sit in a
     # collective with a dead peer until the guard expires): the parents' store carries the flag
