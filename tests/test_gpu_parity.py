@@ -252,6 +252,29 @@ def test_rollout_cartesian_coupled(oracle, n_robots, per_link, dynamic, kernel):
     assert torch.equal(h.rollout_cartesian_coupled(t(batch["q"]), t(batch["qdot"]), t(batch["params"])), avg)
 
 
+@pytest.mark.parametrize("per_link", [0, 1])
+def test_rollout_cartesian_coupled_float32_tile(oracle, per_link):
+    """The LDS-tile form of the coupled Cartesian rollout in float32 (link-origin table and one offset sphere per link)
+    against the float64 oracle, and bit-identical between two calls."""
+    cfg = config.panda_config(n_robots=3, horizon=8, scalar=abi.F32)
+    cfg.kernel_select = 1
+    if per_link:
+        links, offs = config.sphere_offsets_per_link(per_link)
+        config.set_spheres(cfg, links, offs)
+    batch = scenarios.panda_batch(cfg, 50, seed=47, x_min=0.25)
+    c64 = cfg.copy()
+    c64.scalar = abi.F64
+    sx, sv, _ = oracle.fk_spheres(c64, batch["q"], batch["qdot"])
+    o = scenarios.other_robot_obstacles(c64, batch, sx, sv, None)
+    want_avg, _, want_qd = oracle.rollout_cartesian(c64, batch["q"], batch["qdot"], batch["params"], *o, traj=True)
+    h = FabricHandle(cfg, 0)
+    t = h.tensor
+    avg, _, tqd = h.rollout_cartesian_coupled(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), want_traj=True)
+    assert avg.dtype == torch.float32
+    assert relerr(avg.double().cpu().numpy(), want_avg) < 2e-3 and relerr(tqd.double().cpu().numpy(), want_qd) < 2e-3
+    assert torch.equal(h.rollout_cartesian_coupled(t(batch["q"]), t(batch["qdot"]), t(batch["params"])), avg)
+
+
 def test_fk_spheres_with_offsets(oracle):
     cfg = config.panda_config(n_robots=3, horizon=1)
     links, offs = config.sphere_offsets_per_link(4)
