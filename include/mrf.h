@@ -104,7 +104,9 @@ typedef struct {
   mrf_leaf_fn collision_geometry, collision_finsler;
   mrf_leaf_fn plane_geometry, plane_finsler;
   mrf_leaf_fn limit_geometry, limit_finsler;
-  int32_t kernel_select; /* coupled kernels: 0 = auto by batch size, 1 = row-per-lane (throughput), 2 = one wave per scenario (latency) */
+  int32_t kernel_select; /* coupled kernels: 0 = auto by batch size, 1 = row-per-lane (throughput), 2 = one wave per scenario
+                          * (latency), 3 = a pair of waves per row, two resident waves per SIMD (joint-space rollout with
+                          * float64, the reference's leaf strings and link-origin spheres; everything else as 1) */
   int32_t ego_link_mask; /* panda7, n_ego == 6: bit (l-3) set = panda_link l (l = 3..8) carries collision and plane leaves --
                             the collision_links list of set_components (EXJ:91-96,123-125; the Cartesian rollout class
                             defaults to link 7 alone, FPC:20-21).  0x3F = all six (the examples' setting). */
@@ -282,11 +284,13 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
 /* Waits for the stream of the last mrf_rollout_sharded and reports a timed-out exchange (MRF_E_LAUNCH) or MRF_OK. */
 int mrf_comm_status(mrf_handle* h);
 /* Makes a communicator usable again after a timed-out PEER exchange: synchronises this rank's stream, clears the error
- * word and the flags in this rank's exchange buffer and restarts the sequence numbers in a new EPOCH (the reset count
- * is the high part of every sequence number, so a flag of the old sequence that a slower peer stores after the clearing
- * can satisfy no wait of the new one).  Call it on EVERY rank of the group the same number of times, BETWEEN two
- * barriers of the caller's (no rank may start a mrf_rollout_sharded while another one still resets); afterwards the
- * ranks continue with the same sequence of calls again.  A no-op for the RCCL transport. */
+ * word and the flags in this rank's exchange buffer and restarts the sequence numbers in a new EPOCH.  The reset count
+ * is the high part of every sequence number AND the tag of the error word: a flag of the old sequence that a slower peer
+ * stores after the clearing can satisfy no wait of the new one, and a peer kernel of the old epoch that times out late
+ * writes the OLD tag, which the kernels, the commit pass and mrf_comm_status of the new epoch do not take for an error.
+ * Call it on EVERY rank of the group the same number of times, BETWEEN two barriers of the caller's (no rank may start a
+ * mrf_rollout_sharded while another one still resets); afterwards the ranks continue with the same sequence of calls
+ * again.  A no-op for the RCCL transport. */
 int mrf_comm_reset(mrf_handle* h);
 #define MRF_PEER_TIMEOUT_DEFAULT_MS 10000 /* bounded flag wait of the PEER kernel; override: env MRF_PEER_TIMEOUT_MS */
 /* env MRF_PEER_DEVICE_SHARE = k: k ranks of a group run on ONE device (single-GPU test setups); the PEER kernel then caps

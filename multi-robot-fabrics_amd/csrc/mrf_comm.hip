@@ -106,6 +106,10 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   const int m01 = LO ? cfg.lo_merge01 : 0, m45 = LO ? cfg.lo_merge45 : 0;
   const int SX = cfg.n_spheres - m01 - m45;
   int* err = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
+  // The error word is tagged with the reset epoch (the high bits of every sequence number, mrf_comm_reset): "broken" means
+  // "holds THIS epoch's tag", so a kernel of the previous epoch that times out late -- after a peer's reset has already
+  // started the next epoch -- cannot break the new sequence with its store.
+  const int etag = (int)(seq0 >> 40) + 1;
 
   PandaState<T> R;
   load_state(rows, row, q_in, qd_in, R);
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
           // Once the group is in error (this rank timed out, or a peer did and said so in this rank's error word) no
           // further flag goes up: the spheres behind it may have been computed from stale data, and the peers must
           // time out -- or see the error -- rather than fold them.
-          const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+          const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
           if (lane < V.G && !broken)
             __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           // ---- wait for the same workgroup of every other rank (bounded: a missing peer must not hang the GPU)
@@ -244,12 +248,12 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
             const unsigned long long* f = peer_flag(V, V.grank, gen, lane, blk);
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-              if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
+              if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
               if (wall_clock64() - t0 > V.timeout_ticks) {
                 // the timeout is the GROUP's: raise the error word of every rank, so that a peer which went on with
                 // this rank's (now missing) spheres cannot return a finite result either
                 for (int g = 0; g < V.G; ++g)
-                  __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
               }
               __builtin_amdgcn_s_sleep(1);
@@ -279,8 +283,8 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 // After k_rollout_peer (same stream): one thread latches the error word, then every row is committed from that latch --
 // all rows advance, or (a timed-out exchange: some step folded stale spheres) none does and the velocity signal is NaN,
 // so that a caller that forgets mrf_comm_status cannot take the result for a rollout.
-__global__ void k_peer_latch(const int* __restrict__ err, int* __restrict__ latch, int group) {
-  *latch = group > 1 ? __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+__global__ void k_peer_latch(const int* __restrict__ err, int* __restrict__ latch, int group, int etag) {
+  *latch = group > 1 ? (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) : 0;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_peer_commit(int64_t rows, const int* __restrict__ latch, const T* __restrict__ q_st,
@@ -678,7 +682,8 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         if (int rc = launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen, (const T*)q_io,
                             (const T*)qdot_io, (const T*)params, q_st, qd_st, avg_st, seq0))
           return rc;
-        if (int rc = launch(h, mrf::k_peer_latch, dim3(1), dim3(1), st, (const int*)(c->local + c->off_err), latch, c->world))
+        if (int rc = launch(h, mrf::k_peer_latch, dim3(1), dim3(1), st, (const int*)(c->local + c->off_err), latch, c->world,
+                            (int)(seq0 >> 40) + 1))
           return rc;
         return launch(h, mrf::k_peer_commit<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, rows, (const int*)latch,
                       (const T*)q_st, (const T*)qd_st, (const T*)avg_st, (T*)q_io, (T*)qdot_io, (T*)avg_vel_out);
@@ -728,7 +733,7 @@ int mrf_comm_status(mrf_handle* h) {
   if (c->transport == MRF_TRANSPORT_PEER) {
     int err = 0;
     if (int rc = check_hip(h, hipMemcpy(&err, c->local + c->off_err, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy")) return rc;
-    if (err) return fail(h, MRF_E_LAUNCH, "peer exchange timed out: a rank of the group did not publish its spheres "
+    if (err == (int)c->epoch + 1) return fail(h, MRF_E_LAUNCH, "peer exchange timed out: a rank of the group did not publish its spheres "
                                           "(different call sequence, a dead peer, or kernels that cannot run concurrently)");
   }
   return MRF_OK;

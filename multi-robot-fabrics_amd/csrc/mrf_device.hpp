@@ -86,20 +86,37 @@ __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_r
 
 // exp for |x| < 700 without the overflow / subnormal paths of the library version (all arguments here are
 // bounded: -(a r)^2, -s x with x a barrier distance, tanh arguments): x = n ln2 + r, Taylor to r^12 (|r| <= 0.35).
+// A float64 literal cannot be an operand of a vector instruction: the compiler builds it in a VGPR pair, hoists that out of
+// every loop and, in a kernel that is short of registers, keeps it in scratch memory (the exp polynomial alone is 13 of
+// them; k_rollout_panda_wp reloaded ~60 per step).  MRF_SC(v) builds the literal in an SGPR pair instead (two s_mov_b32,
+// opaque to the optimizer), which a VOP3 instruction reads directly as its one scalar operand.
+template <long long BITS>
+__device__ __forceinline__ double sgpr_const() {
+  int lo, hi;
+  asm("s_mov_b32 %0, %1" : "=s"(lo) : "n"((int)(BITS & 0xffffffffLL)));
+  asm("s_mov_b32 %0, %1" : "=s"(hi) : "n"((int)(BITS >> 32)));
+  return __hiloint2double(hi, lo);
+}
+#ifdef MRF_NO_SGPR_CONST
+#define MRF_SC(v) (v)
+#else
+#define MRF_SC(v) (::mrf::sgpr_const<__builtin_bit_cast(long long, (double)(v))>())
+#endif
+
 __device__ __forceinline__ double fast_exp(double x) {
-  const double n = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(-n, 0.6931471803691238, x);
-  r = __builtin_fma(-n, 1.9082149292705877e-10, r);
-  double p = 1.0 / 479001600.0;
-  p = __builtin_fma(p, r, 1.0 / 39916800.0);
-  p = __builtin_fma(p, r, 1.0 / 3628800.0);
-  p = __builtin_fma(p, r, 1.0 / 362880.0);
-  p = __builtin_fma(p, r, 1.0 / 40320.0);
-  p = __builtin_fma(p, r, 1.0 / 5040.0);
-  p = __builtin_fma(p, r, 1.0 / 720.0);
-  p = __builtin_fma(p, r, 1.0 / 120.0);
-  p = __builtin_fma(p, r, 1.0 / 24.0);
-  p = __builtin_fma(p, r, 1.0 / 6.0);
+  const double n = __builtin_rint(x * MRF_SC(1.4426950408889634));
+  double r = __builtin_fma(-n, MRF_SC(0.6931471803691238), x);
+  r = __builtin_fma(-n, MRF_SC(1.9082149292705877e-10), r);
+  double p = MRF_SC(1.0 / 479001600.0);
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 39916800.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 3628800.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 362880.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 40320.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 5040.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 720.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 120.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 24.0));
+  p = __builtin_fma(p, r, MRF_SC(1.0 / 6.0));
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
@@ -257,7 +274,10 @@ struct PandaKin {
 };
 
 // Unrolled walk of the own robot; all tables are compile-time so zero offsets and quarter-turn rolls fold away.
-template <typename T>
+// JSTOP < 7: the walk ends at the origin of joint JSTOP (o, vo, ao of that joint are set, its axis is not): the part of
+// the chain a wave that owns only the proximal collision points needs (k_rollout_panda_wp); cq / sq / qd of joints
+// >= JSTOP are not read.
+template <typename T, int JSTOP = 7>
 __device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, const T (&cq)[7], const T (&sq)[7],
                                                const T (&qd)[7], PandaKin<T>& K) {
   T X[3] = {mount[0], mount[4], mount[8]}, Y[3] = {mount[1], mount[5], mount[9]}, Z[3] = {mount[2], mount[6], mount[10]};
@@ -290,6 +310,15 @@ __device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, cons
         K.p8[k] = o[k];
         K.v8[k] = vo[k];
         K.a8[k] = ao[k];
+      }
+      break;
+    }
+    if (JSTOP < 7 && j == JSTOP) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        K.o[j][k] = o[k];
+        K.vo[j][k] = vo[k];
+        K.ao[j][k] = ao[k];
       }
       break;
     }
@@ -1074,13 +1103,8 @@ __host__ __device__ __forceinline__ int lo_count(int slot, int m01, int m45) {
 // The link-origin kernels keep the own chain's kinematics alive across the sphere loop (single walk) only with the
 // compile-time leaf policies; the runtime-family leaves need the registers, there the chain is re-walked instead
 // (the single-walk form spilled 544 B of scratch per lane in the generic instantiation).
-#ifdef MRF_PAIR_TWO_WALKS  // experiment: the pair-symmetric loop with the chain re-walked after it (frees ~190 registers)
-template <class LS>
-constexpr bool kSingleWalk = false;
-#else
 template <class LS>
 constexpr bool kSingleWalk = !LS::Collision::generic;
-#endif
 
 
 // ------------------------------------------------------------------------------------ planar point robot

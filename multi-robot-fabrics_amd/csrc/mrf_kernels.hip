@@ -261,9 +261,6 @@ __global__ __launch_bounds__(256) MRF_ATTR_ACTION void k_action_panda(const DevC
   }
 }
 
-#ifdef MRF_OBST_RING  // experiment (tools/build_variant.sh ring - -DMRF_OBST_RING): obstacles prefetched by LDS-DMA, not shipped
-#include "experiments/obstacle_ring.hpp"
-#endif
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_action_planar(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
@@ -427,9 +424,6 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
   if (m < M) accumulate_obstacle<CL>(cfg, E, bufA, bufA + 3, bufA + 6, bufA[9], false, acc, bufA[10]);  // odd count
 }
 
-#ifdef MRF_PAIR_SYMMETRY  // experiment build (profiles/r04_experiments.json): measured slower, not part of the shipped kernels
-#include "experiments/pair_symmetry.hpp"
-#endif
 
 // Generic sphere tables (offset spheres, any count): every lane walks ITS OWN chain once, emitting its spheres in
 // table order; they are exchanged CH at a time through a [CH][9][64] LDS tile (18 KB in f64) and each lane folds the
@@ -568,12 +562,6 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
       panda_solve_row<LS, kSingleWalk<LS>>(
           cfg, mount_own, R, P,
           [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-#ifdef MRF_PAIR_SYMMETRY  // experiment build: odd N >= 3, both coincident pairs merged (not checked here)
-            if constexpr (!LS::Collision::generic) {
-              obstacles_from_tile_paired<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
-              return;
-            }
-#endif
             obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
           },
           qdd, act,
@@ -618,6 +606,10 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
     stamp[3] = (long long)wall_clock64();
   }
 }
+
+}  // namespace mrf
+#include "mrf_rollout_wp.hpp"  // k_rollout_panda_wp: the same rollout as a pair of waves per row, two waves per SIMD
+namespace mrf {
 
 // Fold for the coupled Cartesian rollout: the tile holds the other robots' spheres as they are at the START of the horizon
 // (x0 in rows s*9 + 0..2, v in rows s*9 + 3..5); a sphere is folded at x0 + tk v with zero acceleration (FPC:33,448-453) --
@@ -1187,9 +1179,6 @@ __global__ __launch_bounds__(64) void k_coop_panda(const DevCfg<T>* __restrict__
   if (COOP_ROLLOUT && writer) avg_out[row] = sumsq / (T)(H * 7);
 }
 
-#ifdef MRF_COOP4  // experiment (tools/build_variant.sh c4 - -DMRF_COOP4): four waves per scenario, measured slower, not shipped
-#include "experiments/coop4.hpp"
-#endif
 
 // ---------------------------------------------------------------------------- Cartesian rollout
 // RES: the first CART_RESIDENT<T> obstacles live in LDS for the whole rollout (one wave per block); RES = false is the
@@ -1594,10 +1583,8 @@ std::string validate(const mrf_config& c) {
   if (c.model == MRF_MODEL_PANDA7 && (c.n_goals < 0 || c.n_goals > 3)) return "panda n_goals must be 0..3";
   if (c.model == MRF_MODEL_PLANAR3 && (c.n_goals < 0 || c.n_goals > 1)) return "planar3 n_goals must be 0..1";
   if (c.obst_dim != 2 && c.obst_dim != 3) return "obst_dim must be 2 or 3";
-#ifdef MRF_COOP4
-  if (c.kernel_select == 3) return "";
-#endif
-  if (c.kernel_select < 0 || c.kernel_select > 2) return "kernel_select must be 0 (auto), 1 (row-per-lane) or 2 (cooperative)";
+  if (c.kernel_select < 0 || c.kernel_select > 3)
+    return "kernel_select must be 0 (auto), 1 (row-per-lane), 2 (cooperative) or 3 (wave pair per row)";
   if (!(c.dt > 0) || !(c.eps > 0)) return "dt and eps must be positive";
   int prev = 0;
   for (int s = 0; s < c.n_spheres; ++s) {
@@ -1620,43 +1607,11 @@ std::string validate(const mrf_config& c) {
 // scenario ~4x sooner; they win while the row-per-lane grid cannot fill the chip.  cfg.kernel_select overrides.
 bool use_coop(const mrf_handle* h, int64_t n_scen) {
   if (5 * h->cfg.n_robots > 64) return false;
-  if (h->cfg.kernel_select == 1) return false;
-  if (h->cfg.kernel_select >= 2) return true;
+  if (h->cfg.kernel_select == 1 || h->cfg.kernel_select == 3) return false;
+  if (h->cfg.kernel_select == 2) return true;
   return n_scen <= h->coop_max_scen;
 }
 
-#ifdef MRF_COOP4
-// Four waves per scenario (k_coop4_panda, experiments/coop4.hpp): while the batch does not give every CU a scenario, a scenario
-// may as well have the CU's four SIMDs.  Joint-space rollout and coupled compute_action, up to six robots.
-// MRF_COOP4=0 keeps the one-wave form in auto mode (A/B).
-bool use_coop4(const mrf_handle* h, int64_t n_scen) {
-  static const bool off = [] {
-    const char* e = getenv("MRF_COOP4");
-    return e && e[0] == '0';
-  }();
-  if (h->cfg.n_robots > 6) return false;
-  if (h->cfg.kernel_select == 3) return true;
-  return h->cfg.kernel_select == 0 && !off && n_scen <= h->n_cus;
-}
-
-template <bool ROLLOUT>
-int launch_coop4(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, const void* prm, int use_accel, void* avg,
-                 void* traj_q, void* traj_qd, void* qdd_out, void* act_out, hipStream_t st) {
-  const bool lo = is_link_origin_table(h->cfg);
-  const int S = lo ? 8 : h->cfg.n_spheres;
-  return dispatch(h, [&](auto t, auto cl) {
-    using T = decltype(t);
-    using LS = decltype(cl);
-    const size_t lds = sizeof(T) * mrf::coop4_lds_scalars(h->cfg.n_robots, S);
-    if (lds > 64 * 1024) return fail(h, MRF_E_CONFIG, "sphere table too large for the four-wave kernel");
-    dim3 block(256), grid((unsigned)n_scen);
-    auto k = lo ? mrf::k_coop4_panda<T, LS, true, ROLLOUT> : mrf::k_coop4_panda<T, LS, false, ROLLOUT>;
-    hipLaunchKernelGGL(k, grid, block, lds, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q, (const T*)qd,
-                       (const T*)prm, use_accel, (T*)avg, (T*)traj_q, (T*)traj_qd, (T*)qdd_out, (T*)act_out);
-    return check_hip(h, hipGetLastError(), "kernel launch");
-  });
-}
-#endif
 
 template <bool ROLLOUT, bool CART = false>
 int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, const void* prm, int use_accel, void* avg,
@@ -1673,6 +1628,24 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
                        (const T*)prm, use_accel, (T*)avg, (T*)traj_q, (T*)traj_qd, (T*)qdd_out, (T*)act_out);
     return check_hip(h, hipGetLastError(), "kernel launch");
   });
+}
+
+// The wave-pair form of the joint-space rollout (mrf_rollout_wp.hpp): float64, the reference's leaf strings and full
+// collision-link set, the link-origin sphere table with equal radii on the coincident origins.  Selected by
+// mrf_config.kernel_select = 3 (anything it does not cover runs the row-per-lane kernel), or for every handle by the
+// environment variable MRF_ROLLOUT_WP=1 (A/B on one box).  Not the default: measured 5-7 % slower than the row-per-lane
+// kernel on BASELINE config 4 (profiles/r05_wp_*.json).
+bool wave_pair_applies(const mrf_handle* h) {
+  static const bool env_on = [] {
+    const char* e = getenv("MRF_ROLLOUT_WP");
+    return e && e[0] == '1';
+  }();
+  if (h->cfg.kernel_select != 3 && !(env_on && h->cfg.kernel_select != 2)) return false;
+  const mrf_config& c = h->cfg;
+  if (c.scalar != MRF_F64 || !is_panda_leafset(c) || !is_link_origin_table(c)) return false;
+  if (c.n_ego != MRF_N_EGO) return false;
+  if (c.sphere_radius[0] != c.sphere_radius[1] || c.sphere_radius[4] != c.sphere_radius[5]) return false;
+  return true;
 }
 
 }  // namespace
@@ -1714,6 +1687,11 @@ extern "C" {
 
 int mrf_abi_version(void) { return MRF_ABI_VERSION; }
 
+#ifdef MRF_WP_CLOCKS
+int mrf_debug_wp_clocks(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mrf::mrf_wp_clocks), sizeof(long long) * (n < 32 ? n : 32)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef MRF_COOP_CLOCKS
 int mrf_debug_clocks(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(mrf::mrf_dbg_clocks), sizeof(long long) * (n < 32 ? n : 32)) == hipSuccess ? 0 : -1;
@@ -1844,19 +1822,6 @@ void mrf_destroy(mrf_handle* h) {
 
 const char* mrf_last_error(const mrf_handle* h) { return h ? h->err.c_str() : "null handle"; }
 
-#ifdef MRF_OBST_RING
-// ObstRing's preconditions: whole 16-byte pieces (aligned arrays), whole 64-row blocks, 32-bit obstacle strides; MRF_NO_RING=1 keeps the register-pipelined kernels (A/B, tools/prof_kernels.py)
-static bool ring_applies(const mrf_handle* h, int64_t elem, int64_t rows, int n_obst, const void* ox, const void* ov,
-                         const void* oa, const void* orad) {
-  static const bool off = [] {
-    const char* e = getenv("MRF_NO_RING");
-    return e && e[0] == '1';
-  }();
-  if (off || n_obst < 1 || h->cfg.n_ego <= 0) return false;
-  const uintptr_t bits = (uintptr_t)ox | (uintptr_t)ov | (uintptr_t)oa | (uintptr_t)orad;
-  return bits % 16 == 0 && rows % 64 == 0 && rows * 3 * elem < (int64_t)0xFFFFFFFFu;
-}
-#endif
 
 int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* qdot, const void* params,
                        int32_t n_obst, int32_t n_obst_static, const void* ox, const void* ov, const void* oa,
@@ -1883,16 +1848,6 @@ int mrf_compute_action(mrf_handle* h, int64_t rows, const void* q, const void* q
                     (const T*)params, (int)n_obst, (int)n_obst_static, (const T*)ox, (const T*)ov, (const T*)oa,
                     (const T*)orad, (T*)qddot_out, (T*)action_out);
     };
-#ifdef MRF_OBST_RING
-    // obstacles prefetched through the LDS ring when the arrays allow 16-byte DMA pieces (ObstRing)
-    if (ring_applies(h, (int64_t)sizeof(T), rows, n_obst, ox, ov, oa, orad)) {
-      const int64_t nb = rows / 64, resident = 4 * (int64_t)h->n_cus;  // persistent: one wave per SIMD
-      grid = dim3((unsigned)(nb < resident ? nb : resident));
-      block = dim3(64);
-      if (oa) return go(mrf::k_action_panda_ring<T, LS, true>);
-      return go(mrf::k_action_panda_ring<T, LS, false>);
-    }
-#endif
     // no obstacle accelerations (obst_a == NULL; the reference's drivers pass zeros, EXJ:411): 7 loads per obstacle
     if (oa) return go(mrf::k_action_panda<T, LS, true>);
     return go(mrf::k_action_panda<T, LS, false>);
@@ -1907,10 +1862,6 @@ int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scen, const void* q, con
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q || !qdot || !params || !action_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
-#ifdef MRF_COOP4
-  if (use_coop4(h, n_scen))
-    return launch_coop4<false>(h, n_scen, q, qdot, params, (int)use_accel, nullptr, nullptr, nullptr, qddot_out, action_out, st);
-#endif
   if (use_coop(h, n_scen))
     return launch_coop<false>(h, n_scen, q, qdot, params, (int)use_accel, nullptr, nullptr, nullptr, qddot_out, action_out, st);
   const int spw = 64 / h->cfg.n_robots;
@@ -1936,14 +1887,14 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
-#ifdef MRF_COOP4
-  if (use_coop4(h, n_scen))
-    return launch_coop4<true>(h, n_scen, q0, qdot0, params, 1, avg_out, traj_q, traj_qd, nullptr, nullptr, st);
-#endif
   if (use_coop(h, n_scen))
     return launch_coop<true>(h, n_scen, q0, qdot0, params, 1, avg_out, traj_q, traj_qd, nullptr, nullptr, st);
   const int spw = 64 / h->cfg.n_robots;
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+  if (wave_pair_applies(h))
+    return launch(h, mrf::k_rollout_panda_wp<double, LeafSetPanda>, grid, dim3(128), st, (const mrf::DevCfg<double>*)h->dcfg,
+                  n_scen, (const double*)q0, (const double*)qdot0, (const double*)params, (double*)avg_out,
+                  (double*)traj_q, (double*)traj_qd, (long long*)h->clock_probe);
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);

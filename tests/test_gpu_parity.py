@@ -128,7 +128,8 @@ def test_compute_action_planar(oracle, obst_dim):
     assert relerr(act.cpu().numpy(), want_act) < F64_RTOL
 
 
-@pytest.mark.parametrize("kernel", [1, 2])        # 1 = row-per-lane (throughput), 2 = one wave per scenario (latency)
+@pytest.mark.parametrize("kernel", [1, 2, 3])     # 1 = row-per-lane (throughput), 2 = one wave per scenario (latency),
+                                                   # 3 = wave pair per row (float64; float32 falls back to 1)
 @pytest.mark.parametrize("scalar", [abi.F64, abi.F32])
 @pytest.mark.parametrize("n_robots,horizon,n_scen,mask,dynamic", [
     (2, 20, 37, 0, 1),        # BASELINE config 3: 2-Panda RF H=20
