@@ -57,11 +57,13 @@ def spawn_ranks(argv, n):
     rc = proc.wait()
     # exit code SHARD_TIMEOUT_RC from the ranks = "the headline line is complete, the secondary robot-sharded block timed out
     # and the ranks left without tearing the process group down": the line is relayed and the code passed on
+    # -- trusted only when rank 0 SAYS so in the line's own "exit_code" field: benign setup notes inside the block (RCCL not
+    # found, ...) are text, and a rank that dies for an unrelated reason after the line is out keeps the launcher's code
     if rc != 0 and len(json_lines) == 1:
         try:
-            rs = json.loads(json_lines[0]).get("robot_sharded", {})
-            if "error" in rs or any(isinstance(v, dict) and "error" in v for v in rs.values()):
-                rc = SHARD_TIMEOUT_RC
+            declared = json.loads(json_lines[0]).get("exit_code")
+            if isinstance(declared, int) and declared != 0:
+                rc = declared
         except ValueError:
             pass
     if rc == 0 and len(json_lines) != 1:
@@ -686,6 +688,7 @@ def main():
                     out["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg_roll, cfg_act, batch)
+        out["exit_code"] = exit_code    # what every rank is about to leave with (spawn_ranks relays exactly this)
         emit(out)
     if world > 1:   # the line is out: a peer that has already left must not keep this rank in the teardown
         run_guarded(torch.distributed.destroy_process_group, 30.0, lambda: os._exit(SHARD_TIMEOUT_RC))

@@ -20,6 +20,21 @@
  *   - Calls are asynchronous on the given hipStream_t (passed as void*; NULL = default stream).
  *   - Return 0 on success, a negative mrf_status otherwise; mrf_last_error() gives text.
  *   - A handle is NOT thread-safe; distinct handles are independent.
+ *
+ * Numerical contract
+ *   - float64 results agree with the float64 CPU restatement (oracle/) to 1e-9 relative on every row whose barrier
+ *     coordinates are positive: x = d/(r_o + r_b) - 1 of every collision leaf, the plane leaves' clearance, every joint's
+ *     distance to its limits (tests/test_gpu_parity.py; error against the smallest x: tests/test_gpu_error_curve.py).
+ *   - The solve kernels are compiled with -ffast-math (finite-math-only, re-association; the control-step unit --
+ *     deadlock logic, state machine -- is not).  The reference's barrier strings are even powers of 1/x with no clamp
+ *     (EXJ:88-89), so a row with a coordinate x <= 0 -- overlapping spheres, a point below the plane, a joint past its limit
+ *     -- has no meaningful result in the reference either; here such a row returns UNSPECIFIED values, finite or not (a NaN
+ *     is not guaranteed to propagate).  mrf_deadlock_step counts non-finite rollout averages (MRF_DL_NONFINITE) and treats
+ *     them as "no deadlock", as the reference's comparison would.
+ *   - Such a row cannot reach the rows of OTHER scenarios: the kernels share per-wave exchange tiles, but a scenario's
+ *     rows read only their own scenario's entries; every other row's output is bit-identical to a run without the bad
+ *     row (tests/test_gpu_fastmath_contract.py).  Within its scenario every robot is affected from the next rollout step
+ *     on, as in the reference's coupled recurrence (FPJ:211-233).
  */
 #ifndef MRF_H_
 #define MRF_H_
@@ -167,7 +182,9 @@ int mrf_rollout(mrf_handle* h, int64_t n_scenarios, const void* q0, const void* 
 /* The clock the LAST row-per-lane mrf_rollout of this handle ran at, measured inside the kernel: its first and its last
  * workgroup stamp the shader-cycle counter (s_memtime) and the constant-rate wall clock (s_memrealtime) on entry and on
  * exit.  Synchronises the device.  out[i], i < n <= MRF_ROLLOUT_CLOCK_N:
- *   0, 1  shader clock [GHz] seen by the first / last workgroup (0: no rollout yet, or the cooperative kernel ran)
+ *   0, 1  shader clock [GHz] seen by the first / last workgroup (0: no rollout yet, or the LAST mrf_rollout took a
+ *         cooperative kernel, which does not stamp -- the stamps carry the serial number of the call they belong to; a grid
+ *         of one workgroup fills both)
  *   2, 3  lifetime of that workgroup [ms]      4  wall-clock rate [GHz]
  * Two boxes (or two runs) whose kernel times differ can be told apart by it: same cycles at a lower clock, or more cycles. */
 #define MRF_ROLLOUT_CLOCK_N 5

@@ -278,6 +278,11 @@ class PandaCell:
             cfg_rollout = _coupled_config(params, None, params.N_HORIZON, dynamic)
         elif rollouts is not None:
             raise MrfError("rollouts: None, 'jointspace' or 'cartesian'")
+        if rollouts == "cartesian" and estimate == "rollouts":
+            # no Cartesian rollout kernel reads goal_estimate_mask: the reference applies the estimate in the driver
+            # (EXC:355-357), which is estimate='reference' here
+            raise MrfError("estimate='rollouts' is defined for joint-space rollouts only; Cartesian rollouts take "
+                           "estimate='reference' (the driver-side estimate of EXC:355-357) or 'off'")
         if cfg_rollout is not None and estimate != "off":
             cfg_rollout.goal_estimate_mask = ((1 << params.nr_robots) - 1) & ~1 if estimate == "rollouts" else 0b10
         if deadlock is None:

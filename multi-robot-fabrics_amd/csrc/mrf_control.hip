@@ -859,7 +859,8 @@ int mrf_episode_run(mrf_handle* hr, mrf_handle* ha, int64_t n_scen, int32_t n_st
     return rc;
   };
   if (hr && hr->episode_rollout_kind == MRF_ROLLOUT_CARTESIAN && hr->cfg.n_robots > 1 && hr->cfg.n_spheres > 0 &&
-      !mrf_host::coop_applies(hr, n_scen)) {
+      !mrf_host::coop_applies(hr, n_scen) && !mrf_host::cartesian_tile_applies(hr)) {
+    // only the obstacle-array form needs the work buffer (the cooperative and the tile forms keep the spheres on chip)
     if (int rc = cart_work_ensure(hr, n_scen)) {  // outside any capture: the captured step must not allocate
       if (ha->err.empty()) ha->err = hr->err;
       return rc;

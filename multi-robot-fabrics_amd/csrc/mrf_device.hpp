@@ -21,7 +21,17 @@
 
 #include "../../include/mrf.h"
 
+// MRF_SGPR_CONST (set by the translation units whose kernels run at two waves per SIMD, mrf_rollout_wp.hip): float64
+// literals of the math helpers are built in SGPR pairs, see MRF_SC below.  The two flavours of this header live in
+// different inline namespaces, so a library that links both holds two distinct sets of inline functions.
+#ifdef MRF_SGPR_CONST
+#define MRF_DEVICE_FLAVOUR sgpr_literals
+#else
+#define MRF_DEVICE_FLAVOUR vgpr_literals
+#endif
+
 namespace mrf {
+inline namespace MRF_DEVICE_FLAVOUR {
 
 constexpr int NG = 5;  // distinct ego collision points of a Panda: links 3, 4, 5(=6), 7, 8
 
@@ -97,10 +107,10 @@ __device__ __forceinline__ double sgpr_const() {
   asm("s_mov_b32 %0, %1" : "=s"(hi) : "n"((int)(BITS >> 32)));
   return __hiloint2double(hi, lo);
 }
-#ifdef MRF_NO_SGPR_CONST
-#define MRF_SC(v) (v)
-#else
+#ifdef MRF_SGPR_CONST
 #define MRF_SC(v) (::mrf::sgpr_const<__builtin_bit_cast(long long, (double)(v))>())
+#else
+#define MRF_SC(v) (v)  // one wave per SIMD: the literals sit in AGPRs, and every s_mov would cost that wave an issue slot
 #endif
 
 __device__ __forceinline__ double fast_exp(double x) {
@@ -1164,4 +1174,5 @@ __device__ __forceinline__ void planar_finish_row(const DevCfg<T>& cfg, const Pl
   finish<T, 3>(cfg, R.qd, forced, alpha_g, hg, hf, xpsi, qdd, act);
 }
 
+}  // inline namespace
 }  // namespace mrf

@@ -50,7 +50,8 @@ struct mrf_handle {
   } rec;
   // mrf_rollout_cartesian_coupled (mrf_control.hip): obstacle arrays assembled on the device, grown on demand (never
   // inside a stream capture: mrf_episode_run sizes them before it captures)
-  void* clock_probe = nullptr;  // 8 x int64 written by the first / last workgroup of k_rollout_panda (mrf_rollout_clock)
+  void* clock_probe = nullptr;  // 8 x int64 written by the first / last workgroup of k_rollout_panda (mrf_rollout_clock) + the call serial
+  long long rollout_serial = 0;  // mrf_rollout calls on this handle; the stamping kernels copy it into clock_probe[8]
   void* cart_work = nullptr;
   size_t cart_work_bytes = 0;
   int episode_rollout_kind = 0;  // mrf_episode_set_rollout: which rollout an episode on this ROLLOUT handle runs
@@ -156,8 +157,12 @@ int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_
 bool coop_applies(const mrf_handle* h, int64_t n_scen);  // the batch-size / kernel_select rule of the coupled entry points
 int rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
                            void* traj_q, void* traj_qd, void* stream);
+bool cartesian_tile_applies(const mrf_handle* h);  // rollout_cartesian_tile will take the call (no obstacle work buffer needed)
 int rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
                            void* traj_q, void* traj_qd, void* stream);
+// the joint-space rollout as a pair of waves per row (mrf_rollout_wp.hip); the caller has checked that the form applies
+int rollout_wave_pair(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
+                      void* traj_q, void* traj_qd, void* stream);
 // frees h->comm (mrf_comm.hip); called by mrf_destroy
 void comm_release(mrf_handle* h);
 // frees h->staging (mrf_hostpath.hip); called by mrf_destroy

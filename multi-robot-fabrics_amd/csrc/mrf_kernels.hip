@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
                                                        const T* __restrict__ q0, const T* __restrict__ qd0,
                                                        const T* __restrict__ prm, T* __restrict__ avg_out,
                                                        T* __restrict__ traj_q, T* __restrict__ traj_qd,
-                                                       long long* __restrict__ probe) {
+                                                       long long* __restrict__ probe, long long serial) {
   __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
   const DevCfg<T>& cfg = *cfgp;
   // clock probe (mrf_rollout_clock): the first and the last workgroup stamp the shader-cycle counter (s_memtime) and the
@@ -500,6 +500,11 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
   if (probing) {
     stamp[0] = (long long)__builtin_readcyclecounter();
     stamp[1] = (long long)wall_clock64();
+    if (blockIdx.x == 0) probe[8] = serial;  // which mrf_rollout call these stamps belong to (mrf_rollout_clock checks it)
+    if (gridDim.x == 1) {                    // one workgroup is first and last: both slots carry its stamps
+      probe[4] = stamp[0];
+      probe[5] = stamp[1];
+    }
   }
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
   const int N = cfg.n_robots;
@@ -604,12 +609,12 @@ __global__ __launch_bounds__(64) void k_rollout_panda(const DevCfg<T>* __restric
   if (probing) {
     stamp[2] = (long long)__builtin_readcyclecounter();
     stamp[3] = (long long)wall_clock64();
+    if (gridDim.x == 1) {
+      probe[6] = stamp[2];
+      probe[7] = stamp[3];
+    }
   }
 }
-
-}  // namespace mrf
-#include "mrf_rollout_wp.hpp"  // k_rollout_panda_wp: the same rollout as a pair of waves per row, two waves per SIMD
-namespace mrf {
 
 // Fold for the coupled Cartesian rollout: the tile holds the other robots' spheres as they are at the START of the horizon
 // (x0 in rows s*9 + 0..2, v in rows s*9 + 3..5); a sphere is folded at x0 + tk v with zero acceleration (FPC:33,448-453) --
@@ -1652,19 +1657,22 @@ bool wave_pair_applies(const mrf_handle* h) {
 
 bool mrf_host::coop_applies(const mrf_handle* h, int64_t n_scen) { return use_coop(h, n_scen); }
 
+bool mrf_host::cartesian_tile_applies(const mrf_handle* h) {
+  static const bool off = [] {
+    const char* e = getenv("MRF_CART_TILE");
+    return e && e[0] == '0';
+  }();
+  return !off && h->cfg.n_robots >= 2 && h->cfg.n_robots <= 64 && h->cfg.mode == MRF_MODE_VEL && h->cfg.n_spheres >= 1 &&
+         (is_link_origin_table(h->cfg) || h->cfg.n_spheres <= 8);
+}
+
 // mrf_rollout_cartesian_coupled with the other robots' start states in the LDS tile (the link-origin table, or any table of
 // up to eight spheres per robot; mode 'vel'); 1 = this form does not apply here.  MRF_CART_TILE=0 keeps the obstacle-array
 // path (A/B).
 int mrf_host::rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
                                      void* avg_out, void* traj_q, void* traj_qd, void* stream) {
-  static const bool off = [] {
-    const char* e = getenv("MRF_CART_TILE");
-    return e && e[0] == '0';
-  }();
   const bool lo = is_link_origin_table(h->cfg);
-  if (off || h->cfg.n_robots < 2 || h->cfg.n_robots > 64 || h->cfg.mode != MRF_MODE_VEL || h->cfg.n_spheres < 1 ||
-      (!lo && h->cfg.n_spheres > 8))
-    return 1;
+  if (!cartesian_tile_applies(h)) return 1;
   const int spw = 64 / h->cfg.n_robots;
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
   return dispatch(h, [&](auto t, auto cl) {
@@ -1687,11 +1695,6 @@ extern "C" {
 
 int mrf_abi_version(void) { return MRF_ABI_VERSION; }
 
-#ifdef MRF_WP_CLOCKS
-int mrf_debug_wp_clocks(long long* out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mrf::mrf_wp_clocks), sizeof(long long) * (n < 32 ? n : 32)) == hipSuccess ? 0 : -1;
-}
-#endif
 #ifdef MRF_COOP_CLOCKS
 int mrf_debug_clocks(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(mrf::mrf_dbg_clocks), sizeof(long long) * (n < 32 ? n : 32)) == hipSuccess ? 0 : -1;
@@ -1795,7 +1798,7 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out) {
     if (e == hipSuccess) e = hipMemcpy(h->dcfg, &d, sizeof(d), hipMemcpyHostToDevice);
   }
   if (e != hipSuccess) return fail(h, MRF_E_DEVICE, std::string("config upload: ") + hipGetErrorString(e));
-  if (hipMalloc(&h->clock_probe, 8 * sizeof(long long)) != hipSuccess || hipMemset(h->clock_probe, 0, 8 * sizeof(long long)) != hipSuccess)
+  if (hipMalloc(&h->clock_probe, 9 * sizeof(long long)) != hipSuccess || hipMemset(h->clock_probe, 0, 9 * sizeof(long long)) != hipSuccess)
     return fail(h, MRF_E_DEVICE, "clock probe buffer");
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id);
@@ -1887,24 +1890,22 @@ int mrf_rollout(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0
   if (n_scen == 0) return MRF_OK;
   if (n_scen < 0 || !q0 || !qdot0 || !params || !avg_out) return fail(h, MRF_E_ARG, "null/negative argument");
   hipStream_t st = (hipStream_t)stream;
+  h->rollout_serial += 1;  // the row kernels stamp it next to their clock probe; a cooperative launch leaves the old one
   if (use_coop(h, n_scen))
     return launch_coop<true>(h, n_scen, q0, qdot0, params, 1, avg_out, traj_q, traj_qd, nullptr, nullptr, st);
   const int spw = 64 / h->cfg.n_robots;
   dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
-  if (wave_pair_applies(h))
-    return launch(h, mrf::k_rollout_panda_wp<double, LeafSetPanda>, grid, dim3(128), st, (const mrf::DevCfg<double>*)h->dcfg,
-                  n_scen, (const double*)q0, (const double*)qdot0, (const double*)params, (double*)avg_out,
-                  (double*)traj_q, (double*)traj_qd, (long long*)h->clock_probe);
+  if (wave_pair_applies(h)) return mrf_host::rollout_wave_pair(h, n_scen, q0, qdot0, params, avg_out, traj_q, traj_qd, stream);
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
     if (is_link_origin_table(h->cfg))
       return launch(h, mrf::k_rollout_panda<T, LS, true>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
                     (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd,
-                    (long long*)h->clock_probe);
+                    (long long*)h->clock_probe, h->rollout_serial);
     return launch(h, mrf::k_rollout_panda<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
                   (const T*)q0, (const T*)qdot0, (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd,
-                  (long long*)h->clock_probe);
+                  (long long*)h->clock_probe, h->rollout_serial);
   });
 }
 
@@ -1912,12 +1913,14 @@ int mrf_rollout_clock(mrf_handle* h, double* out, int32_t n) {
   MRF_CHECK_READY(h);
   if (!out || n < 1) return fail(h, MRF_E_ARG, "null/negative argument");
   if (int rc = check_hip(h, hipDeviceSynchronize(), "hipDeviceSynchronize")) return rc;
-  long long st[8];
+  long long st[9];
   if (int rc = check_hip(h, hipMemcpy(st, h->clock_probe, sizeof(st), hipMemcpyDeviceToHost), "hipMemcpy")) return rc;
   int wall_khz = 100000;
   (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, h->device);
   double vals[MRF_ROLLOUT_CLOCK_N] = {0, 0, 0, 0, (double)wall_khz * 1e-6};
-  for (int b = 0; b < 2; ++b) {
+  // stamps of an OLDER call (the last mrf_rollout took a cooperative kernel, which does not stamp): report none
+  const bool current = h->rollout_serial > 0 && st[8] == h->rollout_serial;
+  for (int b = 0; b < 2 && current; ++b) {
     const double cycles = (double)(st[4 * b + 2] - st[4 * b + 0]), ticks = (double)(st[4 * b + 3] - st[4 * b + 1]);
     if (ticks > 0 && cycles > 0) {
       vals[b] = cycles / ticks * (double)wall_khz * 1e-6;  // shader cycles per wall-clock tick x tick rate [GHz]

@@ -97,7 +97,7 @@ template <typename T, class LS>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_rollout_panda_wp(
     const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, const T* __restrict__ q0, const T* __restrict__ qd0,
     const T* __restrict__ prm, T* __restrict__ avg_out, T* __restrict__ traj_q, T* __restrict__ traj_qd,
-    long long* __restrict__ probe) {
+    long long* __restrict__ probe, long long serial) {
   __shared__ T lds[WP_SCALARS];
   T* const tile = lds;
   T* const park = lds + WP_TILE;
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (probing) {
     stamp[0] = (long long)__builtin_readcyclecounter();
     stamp[1] = (long long)wall_clock64();
+    if (blockIdx.x == 0) probe[8] = serial;  // which mrf_rollout call these stamps belong to
     if (gridDim.x == 1) {  // one workgroup is first and last: both slots carry its stamps
       stamp[4] = stamp[0];
       stamp[5] = stamp[1];

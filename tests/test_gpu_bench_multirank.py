@@ -108,6 +108,7 @@ def test_stuck_secondary_block_cannot_take_the_headline_with_it():
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_spot_check"]["ok"]
+    assert r["exit_code"] == 3      # what the launcher's code is taken from (spawn_ranks), not a guess from error texts
     err = r["robot_sharded"]["error"]
     assert "timeout" in err and "rank 0's child" in err, err
 
@@ -130,6 +131,7 @@ def test_faulting_secondary_block_cannot_take_the_headline_with_it():
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_spot_check"]["ok"] and "roofline" in r
+    assert r["exit_code"] == 3
     assert "rank 1's child: killed by signal 6" in r["robot_sharded"]["error"], r["robot_sharded"]
     assert r["robot_sharded"]["children"][1] == "killed by signal 6"
     assert took < 200, took         # the surviving child was ended by the flag, not by the 240 s guard

@@ -17,6 +17,10 @@ tmp=$(mktemp -d)
 hip="/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC"
 $hip ${KERNEL_FLAGS--ffast-math} "$@" -c -o $tmp/k.o "$src/multi-robot-fabrics_amd/csrc/mrf_kernels.hip" &
 objs="$tmp/k.o"
+if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_rollout_wp.hip" ]; then
+  $hip ${KERNEL_FLAGS--ffast-math} "$@" -c -o $tmp/w.o "$src/multi-robot-fabrics_amd/csrc/mrf_rollout_wp.hip" &
+  objs="$objs $tmp/w.o"
+fi
 if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" ]; then
   $hip -c -o $tmp/c.o "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" &
   objs="$objs $tmp/c.o"

@@ -19,6 +19,7 @@ def short_name(k):
     """Demangled kernel name without its argument list and with the leaf-policy set abbreviated, so that instantiations
     that differ only in their trailing flags (LO, RES, ACC ...) keep distinct keys."""
     k = k.split("(")[0]
+    k = k.replace("mrf::vgpr_literals::", "mrf::").replace("mrf::sgpr_literals::", "mrf::")  # inline namespaces of mrf_device.hpp
     k = k.replace("mrf::LeafSet<mrf::LeafPow<4, 4, 0, 0>, mrf::SLeaf<1, 0, 0, 1, 1>, mrf::SLeaf<0, 1, 0, 1, 1> >", "LS_reference")
     k = k.replace("mrf::LeafSet<mrf::LeafGeneric, mrf::SLeafGeneric, mrf::SLeafGeneric>", "LS_generic")
     return k.replace("void ", "")[:120]
