@@ -218,10 +218,15 @@ def _traffic_entry(prefix):
     return (tj[keys[-1]], keys[-1]) if keys else (None, None)
 
 
+CONFIG_ROUNDS = 6   # whole rounds of the chip's resident waves per `configs` launch, as the headline's batch (a launch of
+                    # two rounds mostly measures its launch and its tail: VERDICT r4)
+
+
 def config_sizes(name, cus):
-    """Scenarios per launch of a `configs` entry: C2 as SURVEY 8d names it, the others two full rounds of resident waves."""
-    n = {"C2": 2, "C3": 2, "C5": 8, "CART": 3, "CARTC": 3}[name]
-    return 65536 if name == "C2" else 2 * cus * 4 * (64 // n)
+    """Scenarios per launch of a `configs` entry: CONFIG_ROUNDS full rounds of resident single-wave workgroups (4 per CU,
+    64 // n_robots scenarios each) for every configuration."""
+    n = {"C2": 2, "C3": 2, "C5": 8, "CART": 3, "CARTC": 3, "CART32": 2, "CARTC32": 2}[name]
+    return CONFIG_ROUNDS * cus * 4 * (64 // n)
 
 
 def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
@@ -251,7 +256,7 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
         bytes_unit = algorithmic_bytes_per_rollout_step(N, S, H, sb)
     elif kind == "rollout_cartesian_coupled":
         launch = lambda: h.rollout_cartesian_coupled(q, qd, prm)
-        units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_cartc_panda"
+        units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_cartc_panda"   # MODE 0 / 1 / 2 by sphere table
         bytes_unit = sb * (28 + 7 * M) + sb * 23 / H                              # what the obstacle-array formulation would move
     else:
         sx, sv, _ = h.fk_spheres(q, qd)

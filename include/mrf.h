@@ -32,9 +32,11 @@
  *     is not guaranteed to propagate).  mrf_deadlock_step counts non-finite rollout averages (MRF_DL_NONFINITE) and treats
  *     them as "no deadlock", as the reference's comparison would.
  *   - Such a row cannot reach the rows of OTHER scenarios: the kernels share per-wave exchange tiles, but a scenario's
- *     rows read only their own scenario's entries; every other row's output is bit-identical to a run without the bad
- *     row (tests/test_gpu_fastmath_contract.py).  Within its scenario every robot is affected from the next rollout step
- *     on, as in the reference's coupled recurrence (FPJ:211-233).
+ *     rows read only their own scenario's entries.  Every other row's output equals a run without the bad row -- bit for
+ *     bit for a single evaluation (compute_action), to round-off (<= 1e-12) for rollouts, whose system_step picks the
+ *     incremental or the full sincos by a wave-wide vote that a diverging row can change
+ *     (tests/test_gpu_fastmath_contract.py).  Within its scenario every robot is affected from the next rollout step on,
+ *     as in the reference's coupled recurrence (FPJ:211-233).
  */
 #ifndef MRF_H_
 #define MRF_H_

@@ -670,6 +670,60 @@ __device__ __forceinline__ void obstacles_from_tile_drift(const DevCfg<T>& cfg, 
   if (m < M) fold(bufA);  // odd count
 }
 
+// Tables of more than eight spheres per robot (the reference's default, n_obst_per_link: 4 -> 32, panda_config.yaml:8,
+// EXC:184): 32 x (x0, v) of 64 lanes are 98 KB, more than a wave's LDS, so the spheres are RE-DERIVED in every step from the
+// robots' START joint states (cos q0, sin q0, qdot0: [21][64], staged once) -- every lane walks its own start chain, emitting
+// its spheres in table order at x0 + tk v; they are exchanged CART_CH at a time through a [CART_CH][6][64] tile and folded by
+// the other lanes of the scenario before the walk moves on (the pattern of obstacles_generic_chunked, without accelerations).
+// ~40 instructions per sphere and step instead of seven loads from the obstacle arrays of k_publish_obstacles.
+constexpr int CART_CH = 8;
+constexpr int CART_ST0 = 21 * 64;
+static_assert(CART_ST0 + CART_CH * 6 * 64 <= TILE_SCALARS, "start states + chunk tile must fit the [72][64] tile's storage");
+
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_start_chunked(const DevCfg<T>& cfg, T* __restrict__ st0, int lane, int ls, int li, int N,
+                                                        const T* __restrict__ mount_own, bool dyn, T tk, const EgoPts<T, NG>& E,
+                                                        EgoAcc<T, NG>& acc) {
+  T* chunk = st0 + CART_ST0;
+  const int S = cfg.n_spheres;
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  panda_walk_spheres<false, T>(
+      cfg, mount_own,
+      [&](int j, T& c, T& s, T& qdj) {
+        c = st0[(3 * j + 0) * 64 + lane];
+        s = st0[(3 * j + 1) * 64 + lane];
+        qdj = st0[(3 * j + 2) * 64 + lane];
+      },
+      [&](int s, const T* x, const T* v, const T*) {
+        const int k = s % CART_CH;
+        if (k == 0) __syncthreads();  // the previous chunk has been folded by every lane
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const T vc = dyn ? v[c] : T(0);
+          chunk[((k * 6) + c) * 64 + lane] = x[c] + tk * vc;   // constant-velocity obstacle (FPC:448-453)
+          chunk[((k * 6) + 3 + c) * 64 + lane] = vc;
+        }
+        if (k != CART_CH - 1 && s != S - 1) return;
+        __syncthreads();
+        const int n = k + 1, s0 = s - k;  // spheres in this chunk, first sphere of the chunk
+        pipelined_pairs<T, 6>(
+            (N - 1) * n,
+            [&](int m, T (&buf)[6]) {
+              const int d = m / n, kk = m - d * n;
+              int jr = li + 1 + d;
+              if (jr >= N) jr -= N;
+              lds_ptr src = (lds_ptr)(chunk + (kk * 6) * 64 + ls * N + jr);
+#pragma unroll
+              for (int c = 0; c < 6; ++c) buf[c] = src[c * 64];
+            },
+            [&](int m, T (&buf)[6]) {
+              const int kk = m % n;
+              const T zero[3] = {T(0), T(0), T(0)};
+              accumulate_obstacle<CL>(cfg, E, buf, buf + 3, zero, cfg.sphere_r[s0 + kk], false, acc);
+            });
+      });
+}
+
 // ---------------------------------------------------------------------------- coupled Cartesian rollout (up to 8 spheres per robot)
 // mrf_rollout_cartesian_coupled at throughput batch sizes: every robot rolls out its OWN fabric against the other robots'
 // spheres as they are at the START of the horizon, moving on at constant velocity (FPC:421-458, EXC:335-357).  Those spheres
@@ -679,18 +733,21 @@ __device__ __forceinline__ void obstacles_from_tile_drift(const DevCfg<T>& cfg, 
 // the whole horizon every fold reads the tile at x0 + k dt v.  No obstacle arrays in HBM (k_publish_obstacles + k_rollout_cart_panda stream 16 obstacles x 7
 // scalars per row and step), no per-step exchange either.  A step is action, then system_step (FPC:77-92); mode 'vel' (the
 // Panda drivers' mode, parameters_manipulators.py:12) -- 'acc' stays with the obstacle-array kernel.
-template <typename T, class LS, bool LO>
+// MODE: 0 = link-origin table (LO), 1 = any table of up to eight spheres (published once), 2 = any table, re-derived from the
+// start states chunk by chunk in every step (obstacles_start_chunked)
+template <typename T, class LS, int MODE>
 __global__ __launch_bounds__(64) void k_rollout_cartc_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                              const T* __restrict__ q0, const T* __restrict__ qd0,
                                                              const T* __restrict__ prm, T* __restrict__ avg_out,
                                                              T* __restrict__ traj_q, T* __restrict__ traj_qd) {
   __shared__ T xch[TILE_SCALARS];
+  constexpr bool LO = MODE == 0;
   const DevCfg<T>& cfg = *cfgp;
   const int lane = threadIdx.x;
   const int nsp = LO ? 8 - cfg.lo_merge01 - cfg.lo_merge45 : cfg.n_spheres;  // distinct spheres per robot
   if constexpr (LO) {
     stage_sphere_radii(cfg, xch, lane);  // visible after the publish barrier
-  } else if (lane < nsp) {
+  } else if (MODE == 1 && lane < nsp) {
     xch[TILE_RADII + lane] = cfg.sphere_r[lane];
     xch[TILE_MULT + lane] = T(1);
   }
@@ -710,7 +767,16 @@ __global__ __launch_bounds__(64) void k_rollout_cartc_panda(const DevCfg<T>* __r
   load_state(rows, row, q0, qd0, R);
   const T* mount_own = cfg.mount[li];
   PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
-  if constexpr (!LO) {
+  if constexpr (MODE == 2) {
+    // start states of every lane, read by joint index in every step's sphere walk (own lane's entries only)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+      xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+      xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+    }
+  }
+  if constexpr (MODE == 1) {
     // Any table: the rolled sphere walk reads the joint state by joint index, so cos q, sin q, qdot are parked in the
     // tile's acceleration rows (j*9 + 6..8, which the Cartesian fold never reads) and the spheres go to the x / v rows.
     // Own lane's entries only until the barrier.
@@ -779,10 +845,13 @@ __global__ __launch_bounds__(64) void k_rollout_cartc_panda(const DevCfg<T>* __r
     if (k > 0) system_step(k - 1);
     const T tk = to_uniform((T)k * cfg.dt);  // elapsed obstacle time
     T qdd[7], act[7];
-    panda_solve_row<LS, kSingleWalk<LS>>(
+    panda_solve_row<LS, kSingleWalk<LS> && MODE != 2>(
         cfg, mount_own, R, P,
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          obstacles_from_tile_drift<typename LS::Collision>(cfg, xch, ls, li, N, nsp, tk, E, acc);
+          if constexpr (MODE == 2)
+            obstacles_start_chunked<typename LS::Collision>(cfg, xch, lane, ls, li, N, mount_own, cfg.dynamic != 0, tk, E, acc);
+          else
+            obstacles_from_tile_drift<typename LS::Collision>(cfg, xch, ls, li, N, nsp, tk, E, acc);
         },
         qdd, act,
         [&](const PandaKin<T>& K1) {
@@ -1662,13 +1731,20 @@ bool mrf_host::cartesian_tile_applies(const mrf_handle* h) {
     const char* e = getenv("MRF_CART_TILE");
     return e && e[0] == '0';
   }();
+  // tables of more than eight spheres per robot keep the obstacle-array path: re-deriving them on chip in every step
+  // (k_rollout_cartc_panda MODE 2) was built and measured 11 % slower at 32 spheres (profiles/r05_cartc32.json);
+  // MRF_CART_CHUNKED=1 selects it for every table (A/B, parity tests)
+  static const bool chunked = [] {
+    const char* e = getenv("MRF_CART_CHUNKED");
+    return e && e[0] == '1';
+  }();
   return !off && h->cfg.n_robots >= 2 && h->cfg.n_robots <= 64 && h->cfg.mode == MRF_MODE_VEL && h->cfg.n_spheres >= 1 &&
-         (is_link_origin_table(h->cfg) || h->cfg.n_spheres <= 8);
+         (is_link_origin_table(h->cfg) || h->cfg.n_spheres <= 8 || chunked);
 }
 
-// mrf_rollout_cartesian_coupled with the other robots' start states in the LDS tile (the link-origin table, or any table of
-// up to eight spheres per robot; mode 'vel'); 1 = this form does not apply here.  MRF_CART_TILE=0 keeps the obstacle-array
-// path (A/B).
+// mrf_rollout_cartesian_coupled with the other robots' spheres kept on chip (mode 'vel'): start spheres in the LDS tile for
+// the link-origin table and for tables of up to eight spheres (larger tables: obstacle arrays, see cartesian_tile_applies);
+// 1 = this form does not apply here.  MRF_CART_TILE=0 keeps the obstacle-array path everywhere (A/B).
 int mrf_host::rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
                                      void* avg_out, void* traj_q, void* traj_qd, void* stream) {
   const bool lo = is_link_origin_table(h->cfg);
@@ -1678,7 +1754,13 @@ int mrf_host::rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* 
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
-    auto k = lo ? mrf::k_rollout_cartc_panda<T, LS, true> : mrf::k_rollout_cartc_panda<T, LS, false>;
+    // MRF_CART_CHUNKED=1: every non-link-origin table is re-derived from the start states in every step (MODE 2)
+    static const bool chunk_all = [] {
+      const char* e = getenv("MRF_CART_CHUNKED");
+      return e && e[0] == '1';
+    }();
+    auto k = lo ? mrf::k_rollout_cartc_panda<T, LS, 0>
+                : ((h->cfg.n_spheres <= 8 && !chunk_all) ? mrf::k_rollout_cartc_panda<T, LS, 1> : mrf::k_rollout_cartc_panda<T, LS, 2>);
     return launch(h, k, grid, block, (hipStream_t)stream, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0, (const T*)qdot0,
                   (const T*)params, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
   });

@@ -170,7 +170,7 @@ def other_robot_obstacles(cfg, batch, spheres_x, spheres_v=None, spheres_a=None)
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE.json configs
-BASELINE_CONFIGS = ("C2", "C3", "C5", "CART", "CARTC")
+BASELINE_CONFIGS = ("C2", "C3", "C5", "CART", "CARTC", "CART32", "CARTC32")
 
 
 def baseline_config(name, scalar=abi.F64):
@@ -183,6 +183,9 @@ def baseline_config(name, scalar=abi.F64):
               robots' link origins at the start state), no obstacle accelerations (FPC:33) -> mrf_rollout_cartesian
         CARTC the same rollout through mrf_rollout_cartesian_coupled, the call the Cartesian example driver makes (EXC:330-399):
               the other robots' start states never leave the chip (LDS tile, k_rollout_cartc_panda)
+        CART32 / CARTC32  the reference's DEFAULT Cartesian example (panda_config.yaml: 2 robots, n_obst_per_link: 4 -> 32 spheres
+              per robot, EXC:184) at H=30: through obstacle arrays (mrf_rollout_cartesian) and through the coupled entry point,
+              which re-derives the other robot's spheres from its start joint state in every step (obstacles_start_chunked)
     -> dict(cfg, kind, batch = keyword arguments of panda_batch, scenarios_per_cu_round, label)."""
     if name == "C2":
         cfg = _config.panda_config(n_robots=2, horizon=1, scalar=scalar)
@@ -206,6 +209,15 @@ def baseline_config(name, scalar=abi.F64):
         cfg = _config.panda_config(n_robots=3, horizon=30, scalar=scalar)
         return dict(cfg=cfg, kind="rollout_cartesian_coupled", batch=dict(x_min=0.1),
                     label="3-Panda Cartesian rollout H=30 against the other robots' spheres (coupled entry point)")
+    if name in ("CART32", "CARTC32"):
+        cfg = _config.panda_config(n_robots=2, horizon=30, scalar=scalar)
+        links, offs = _config.sphere_offsets_per_link(4)
+        _config.set_spheres(cfg, links, offs)
+        if name == "CART32":
+            return dict(cfg=cfg, kind="rollout_cartesian", batch=dict(x_min=0.1),
+                        label="2-Panda Cartesian rollout H=30, M=32 (n_obst_per_link=4) through obstacle arrays")
+        return dict(cfg=cfg, kind="rollout_cartesian_coupled", batch=dict(x_min=0.1),
+                    label="2-Panda Cartesian rollout H=30 against the other robot's 32 spheres (coupled entry point, on chip)")
     raise KeyError(f"unknown baseline configuration {name!r}: {BASELINE_CONFIGS}")
 
 

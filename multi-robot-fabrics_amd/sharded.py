@@ -26,6 +26,7 @@ batching scenarios is what makes the link time matter.  The compute backend is i
 partitioning / gather logic is testable on CPU ranks (tests pass an oracle-backed stand-in); the default backend
 is the HIP kernels and there is no CPU fallback.
 """
+import os
 import time
 
 import torch
@@ -336,4 +337,38 @@ class ShardedRollout:
                         "unit": "GB/s", "frac": link_bytes / per_step / 153e9, "steps": H}}
         top = out["link"] if sr.G > 1 else out["hbm_algorithmic"]
         out.update(achieved=top["achieved"], peak=top["peak"], unit="GB/s", frac=top["frac"], traffic=None)
+        # measured HBM traffic of the transport's kernels (separate --pmc passes, profiles/traffic.json keys
+        # sharded_<transport>_<dtype>: bytes per owned row and rollout step), scaled to this rank's rows
+        tr = ShardedRollout._traffic_entry(f"sharded_{sr.transport}_{'f64' if sb == 8 else 'f32'}")
+        if tr is not None:
+            out["traffic"] = tr["bytes_per_row_step"] * sr.count * B / per_step / 1e9
+            out["traffic_unit"], out["traffic_key"], out["traffic_kernels"] = "GB/s", tr["key"], tr.get("kernels")
+        # Link model, stated so that the first run on real links audits itself: one directed xGMI link
+        # carries cnt_max*SX*9*B scalars per step at <= 153 GB/s; the exchanged step is link-bound once that exceeds the
+        # fixed cost of an exchange (flag round trip of the peer kernel / launch + collective latency of the RCCL path).
+        one = S * 9 * sb                                     # bytes per scenario, link and step with ONE robot per rank
+        cm = sr.cnt_max if sr.G > 1 else 1
+        fixed_us = {"peer": 4.0, "rccl": 25.0}               # assumed fixed cost per exchange [us]: measured 1.7 us flag
+        out["link"].update(                                  # round trip on one die (tools/ipc_probe.hip); RCCL: typical
+            predicted_ms_per_step=cm * one * B / 153e9 * 1e3,
+            predicted_ms_per_rollout=cm * one * B / 153e9 * 1e3 * H,
+            measured_ms_per_step=per_step * 1e3,
+            model={"bytes_per_scenario_link_step": cm * one, "link_GBps": 153.0, "assumed_fixed_us_per_exchange": fixed_us,
+                   "link_bound_above_scenarios": {k: int(v * 1e-6 * 153e9 / (cm * one)) for k, v in fixed_us.items()},
+                   "peer_vs_rccl": "per step the peer kernel costs max(kernel, link) + flag round trip, the RCCL path "
+                                   "predict + all-gather + action in stream order = kernels + latency + link: in this "
+                                   "model the peer transport is ahead at every batch size; the RCCL path can only cross "
+                                   "if the peer kernel's 8-byte remote stores stay below the link rate RCCL reaches -- "
+                                   "compare achieved link GB/s of the two transports at the largest batch"})
         return out
+
+    @staticmethod
+    def _traffic_entry(key):
+        import json
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+        try:
+            with open(path) as f:
+                e = json.load(f).get(key)
+        except (OSError, ValueError):
+            return None
+        return dict(e, key=key) if isinstance(e, dict) and "bytes_per_row_step" in e else None

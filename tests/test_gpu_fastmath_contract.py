@@ -1,7 +1,9 @@
 """The contract of the -ffast-math solve kernels (include/mrf.h, "Numerical contract"): a row whose barrier coordinate is
 <= 0 (spheres overlapping: the reference's even-power barriers, EXJ:88-89, have no meaning there) returns unspecified
 values -- finite or not -- but ONLY that scenario does: the rows of every other scenario, including those that share its
-wave and its LDS exchange tile, are bit-identical to a run without the penetration."""
+wave and its LDS exchange tile, agree with a run without the penetration to round-off (1e-12; not bit for bit: the rollout
+kernels choose between the incremental and the full sincos by a wave-wide vote on |dt*qdot|, and a diverging row changes
+that vote for its wave)."""
 import numpy as np
 import pytest
 import torch
@@ -10,6 +12,7 @@ from multi_robot_fabrics_amd import abi, config, scenarios
 from multi_robot_fabrics_amd.runtime import FabricHandle
 
 pytestmark = pytest.mark.gpu
+RTOL = 1e-12
 
 
 def _batches(cfg, n_scen, bad):
@@ -41,7 +44,8 @@ def test_penetrating_scenario_stays_in_its_rows_rollout(kernel):
     for s in bad:
         keep[s * N:(s + 1) * N] = False
     for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a[..., keep], b[..., keep])          # bit-identical, not merely close
+        assert np.isfinite(b[..., keep]).all()
+        assert np.abs(a[..., keep] - b[..., keep]).max() <= RTOL * np.abs(a[..., keep]).max()
     assert np.isfinite(outs[0][0]).all()
     # the penetrating rows did change (the test would be vacuous otherwise)
     assert not np.array_equal(outs[0][0][~keep], outs[1][0][~keep])
@@ -60,5 +64,5 @@ def test_penetrating_scenario_stays_in_its_rows_coupled_action():
     keep = np.ones(n_scen * N, dtype=bool)
     for s in bad:
         keep[s * N:(s + 1) * N] = False
-    assert np.array_equal(acts[0][:, keep], acts[1][:, keep])
+    assert np.array_equal(acts[0][:, keep], acts[1][:, keep])      # a single evaluation has no wave-wide decision: bit for bit
     assert not np.array_equal(acts[0][:, ~keep], acts[1][:, ~keep])

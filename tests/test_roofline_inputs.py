@@ -17,8 +17,14 @@ def test_traffic_json_equals_its_sources():
         tj = json.load(f)
     checked = 0
     for key, rec in tj.items():
-        if key.startswith("_") or "kernel" not in rec:
+        if key.startswith("_") or ("kernel" not in rec and "kernels" not in rec):
             continue                                   # round-1 record kept for history (hand-entered then)
+        if re.fullmatch(r"sharded_(rccl|peer|torch)_(f64|f32)", key):   # robot-sharded transports: bytes per row and step
+            with open(os.path.join(ROOT, rec["source"])) as f:
+                pmc = json.load(f)
+            want = make_traffic.sharded_entry(pmc, [k for k in rec["kernels"]], rec["rows"], rec["steps_per_launch"])
+            assert rec["bytes_per_row_step"] == want["bytes_per_row_step"], key
+            continue
         m = re.fullmatch(r"rollout_(f64|f32)_N(\d+)_H(\d+)_B(\d+)", key)
         mc = re.fullmatch(r"config_([A-Za-z0-9]+)_(f64|f32)_B(\d+)", key)       # bench.py's `configs` block
         assert m or mc, key

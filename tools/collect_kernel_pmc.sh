@@ -13,7 +13,7 @@ cp $root/gpurun_out/prof_kernels_f64.json $out/prof_kernels_f64.json
 specs=""
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/k_$name -- python3 $root/tools/prof_kernels.py f64 > $out/k_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/k_$name -- python3 $root/tools/prof_kernels.py f64 > $out/k_$name.log 2>&1
   specs="$specs $name=$out/k_$name"
 done
 python3 $root/tools/summarize_prof.py ${tag}_kernels $out/none $root/gpurun_out/profiles $specs > $out/summary_k.log 2>&1

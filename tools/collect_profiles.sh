@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $r
 specs=""
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SMEM SQ_INSTS_VMEM" "SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   name=$(echo $pass | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc_$name -- python3 $root/tools/prof_rollout.py $B $dt 3 > $out/pmc_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc_$name -- python3 $root/tools/prof_rollout.py $B $dt 3 > $out/pmc_$name.log 2>&1
   specs="$specs $name=$out/pmc_$name"
 done
 python3 $root/tools/summarize_prof.py $tag $out/stats $root/gpurun_out/profiles $specs > $out/summary.log 2>&1

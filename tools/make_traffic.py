@@ -41,6 +41,14 @@ def derive(entry, horizon, dtype):
     return out
 
 
+def sharded_entry(pmc, substrings, rows, steps_per_launch):
+    """bytes_per_row_step = sum over the named kernels of (2*FETCH_SIZE + WRITE_SIZE)*1024 / rows / steps_per_launch."""
+    kernels = [pick(pmc, sub) for sub in substrings]
+    total = sum((2.0 * pmc[k]["FETCH_SIZE"] + pmc[k]["WRITE_SIZE"]) * 1024.0 for k in kernels)
+    return {"bytes_per_row_step": total / rows / steps_per_launch, "kernels": [k[:60] for k in kernels], "rows": rows,
+            "steps_per_launch": steps_per_launch}
+
+
 def pick(pmc, substring):
     hits = [k for k in pmc if substring in k and not k.startswith("_")]
     if len(hits) != 1:
@@ -55,7 +63,30 @@ def main():
     ap.add_argument("--horizon", type=int, default=None)
     ap.add_argument("--kernel-substring", default="k_rollout_panda<")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--rows", type=int, default=None, help="sharded_* keys: rows the counted launches worked on")
+    ap.add_argument("--sum-kernels", nargs="+", default=None, help="sharded_* keys: kernel-name substrings whose bytes add up")
+    ap.add_argument("--steps-per-launch", type=int, default=1, help="sharded_* keys: rollout steps one launch covers")
     args = ap.parse_args()
+    ms = re.fullmatch(r"sharded_(rccl|peer|torch)_(f64|f32)", args.key)
+    if ms:
+        # measured HBM bytes per owned row and rollout step of a robot-sharded transport's kernels (sharded.roofline)
+        if not (args.rows and args.sum_kernels):
+            raise SystemExit("sharded_* keys need --rows and --sum-kernels")
+        with open(args.pmc) as f:
+            pmc = json.load(f)
+        rel = os.path.relpath(os.path.abspath(args.pmc), ROOT)
+        rec = sharded_entry(pmc, args.sum_kernels, args.rows, args.steps_per_launch)
+        rec.update(source=rel, kernel_source_sha256=pmc.get("_meta", {}).get("kernel_source_sha256"))
+        tj = {}
+        if os.path.exists(args.out):
+            with open(args.out) as f:
+                tj = json.load(f)
+        tj[args.key] = rec
+        with open(args.out, "w") as f:
+            json.dump(tj, f, indent=1)
+            f.write("\n")
+        print(json.dumps({args.key: rec}, indent=1))
+        return
     m = re.fullmatch(r"rollout_(f64|f32)_N(\d+)_H(\d+)_B(\d+)", args.key)
     mc = re.fullmatch(r"config_([A-Za-z0-9]+)_(f64|f32)_B(\d+)", args.key)
     if m:

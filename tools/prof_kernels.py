@@ -75,6 +75,11 @@ qq, qqd = q.clone(), qd.clone()
 h.step_predict(B, 0, N, qq, qqd, sph)
 report("k_step_action", timed(lambda: h.step_action(B, 0, N, qq, qd.clone(), prm, sph, ssq)), rows,
        sb * (14 + 29 + 9 * SX * (N - 1) + 8), "rows")
+# the peer transport's persistent kernel with a group of one (all robots on this GPU, spheres through memory)
+from multi_robot_fabrics_amd.sharded import ShardedRollout
+sr = ShardedRollout(cfg, 0, 1, device_index=0, transport="peer", max_scenarios=B)
+report("k_rollout_peer (group of one, H=30)", timed(lambda: sr.rollout(q.clone(), qd.clone(), prm), iters=4), rows * H,
+       sb * (28 + 9 * SX * N) + sb * 23 / H, "rollout_steps")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"dtype": dtype, "scenarios": B, "robots": N, "kernels": out},
           open(os.path.join(ROOT, "gpurun_out", f"prof_kernels_{dtype}.json"), "w"), indent=1)
