@@ -256,7 +256,11 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
         bytes_unit = algorithmic_bytes_per_rollout_step(N, S, H, sb)
     elif kind == "rollout_cartesian_coupled":
         launch = lambda: h.rollout_cartesian_coupled(q, qd, prm)
-        units, unit_name, kernel = rows * H, "rollout-steps", "k_rollout_cartc_panda"   # MODE 0 / 1 / 2 by sphere table
+        # link-origin table or <= 8 spheres per robot: start spheres in the LDS tile; larger tables: obstacle arrays assembled on
+        # the device (mrf_host::cartesian_tile_applies; the on-chip re-derivation is opt-in, profiles/r05_cartc32.json)
+        on_chip = S <= 8 or os.environ.get("MRF_CART_CHUNKED") == "1"
+        units, unit_name = rows * H, "rollout-steps"
+        kernel = "k_rollout_cartc_panda" if on_chip else "k_publish_obstacles + k_rollout_cart_panda"
         bytes_unit = sb * (28 + 7 * M) + sb * 23 / H                              # what the obstacle-array formulation would move
     else:
         sx, sv, _ = h.fk_spheres(q, qd)

@@ -5,6 +5,7 @@ overridable field here (DESIGN.md "spec"), so a later session with `fabrics` ins
 configuration rather than by code.
 """
 import math
+import os
 
 import numpy as np
 
@@ -86,6 +87,46 @@ def _common(cfg):
     cfg.plane_abs = 1
     cfg.zero_small_action = 1
     cfg.ego_link_mask = 0x3F        # collision + plane leaves on all of links 3..8
+    _apply_reconciled_fields(cfg)
+
+
+# Reconciled constants (tests/reconcile_constants.py --write): every value the survey could only RECALL from the un-vendored
+# `fabrics` package is a named field or a library string; once the reference's own vectors exist (tests/golden/
+# make_reference_golden.py) the fit is written to a JSON file and picked up here -- no code change.  Looked for at
+# $MRF_CONSTANTS, else multi-robot-fabrics_amd/constants.json; absent = the recalled defaults.  Format:
+#   {"fields": {"attr_k": 5.0, "jdot_sign": -1.0, ...}, "strings": {"limit_finsler": "...", "finsler_plane_constraint": "..."}}
+# strings are LIBRARY defaults: a string the caller passes explicitly (EXJ:87-89) wins.
+CONSTANTS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "constants.json")
+LIBRARY_STRING_KEYS = ("limit_geometry", "limit_finsler", "finsler_plane_constraint")
+
+
+def reconciled_constants():
+    path = os.environ.get("MRF_CONSTANTS") or CONSTANTS_FILE
+    if not os.path.exists(path):
+        return {}
+    import json
+    with open(path) as f:
+        d = json.load(f)
+    unknown = [k for k in d if k not in ("fields", "strings", "_meta")]
+    if unknown:
+        raise ValueError(f"{path}: unknown sections {unknown}")
+    return d
+
+
+def _apply_reconciled_fields(cfg):
+    for k, v in reconciled_constants().get("fields", {}).items():
+        if not hasattr(cfg, k):
+            raise KeyError(f"reconciled constants: unknown mrf_config field {k!r}")
+        setattr(cfg, k, type(getattr(cfg, k))(v))
+
+
+def _library_strings():
+    s = dict(LIBRARY_STRINGS)
+    for k, v in reconciled_constants().get("strings", {}).items():
+        if k not in LIBRARY_STRING_KEYS:
+            raise KeyError(f"reconciled constants: {k!r} is not a library-default string {LIBRARY_STRING_KEYS}")
+        s[k] = v
+    return s
 
 
 def set_strings(cfg, **strings):
@@ -178,7 +219,7 @@ def panda_config(n_robots=2, horizon=10, dynamic=1, n_ego=6, scalar=abi.F64, mou
     for j in range(7):
         cfg.limits[j][0], cfg.limits[j][1] = PANDA_LIMITS[j]
     set_spheres(cfg, list(range(1, 9)))       # 8 link origins, r = 0.08 (PM:23-26)
-    s = dict(LIBRARY_STRINGS)
+    s = _library_strings()
     s.update(PANDA_STRINGS)
     s.update(strings)
     set_strings(cfg, **s)
@@ -200,7 +241,7 @@ def planar3_config(n_robots=4, n_goals=1, obst_dim=3, scalar=abi.F64, **strings)
             for c in range(4):
                 cfg.mount[i][r * 4 + c] = eye[r, c]
     set_spheres(cfg, [1], radii=[0.2])
-    s = dict(LIBRARY_STRINGS)
+    s = _library_strings()
     s.update(POINT_STRINGS)
     s.update(strings)
     set_strings(cfg, **s)

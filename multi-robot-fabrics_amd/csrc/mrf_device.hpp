@@ -735,7 +735,8 @@ __device__ __forceinline__ void attractor(const DevCfg<T>& cfg, const T* x, T w,
   rnorm = r;
   T ar = cfg.attr_a * r;
   twoA = T(2) * ((cfg.attr_mu - cfg.attr_ml) * fast_exp(-ar * ar) + cfg.attr_ml);
-  // grad psi = w k tanh(alpha r) x/r ; 0 at r == 0 (build convention, DESIGN.md "deviations")
+  // grad psi = w k tanh(alpha r) x/r ; 0 at r == 0: for the 1-D attractor that is CasADi's own value (sqrt(sq(x)) -> |x|,
+  // derivative sign(x)); for a 3-D task exactly on its goal it is this build's convention (DESIGN.md "deviations" 1)
   T g = r > T(0) ? w * cfg.attr_k * fast_tanh(cfg.attr_alpha * r) * fast_rcp(r) : T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) f[k] = twoA * g * x[k];

@@ -57,9 +57,12 @@ class _Ca:
 
     @staticmethod
     def norm_2(x):
-        # casadi's d|x|/dx is 0/0 = NaN at x == 0 exactly (the reference's own start pose has
-        # q[6] == x_goal_2 == pi/4).  Build convention: the gradient there is 0 (the limit of the
-        # attractor force tanh(a r) x/r).  Stated in DESIGN.md "deviations".
+        # Gradient at x == 0 exactly: defined as 0 (the limit of the attractor force tanh(a r) x/r).  The
+        # reference's own start pose sits there for the 1-D attractor (q[6] == x_goal_2 == pi/4, PM:93 / EXJ:428)
+        # and evidently runs, so the earlier reading "casadi gives 0/0 = NaN" cannot hold for it: as recalled,
+        # casadi simplifies sqrt(sq(x)) of a scalar to fabs(x), whose derivative sign(x) is 0 at 0 -- this
+        # convention.  A 3-D task exactly on its goal is the only place where casadi may still give 0/0.
+        # DESIGN.md "deviations" 1; tests/reconcile_constants.py enumerates the candidates.
         s = torch.sum(x * x)
         safe = torch.where(s > 0, s, torch.ones_like(s))
         return torch.where(s > 0, torch.sqrt(safe), torch.zeros_like(s))

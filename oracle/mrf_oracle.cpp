@@ -342,18 +342,40 @@ void limit_leaves(const mrf_config& cfg, QSpec& S, int n, const double* q, const
     }
 }
 
+// How ca.norm_2(x) of the attractor strings behaves at / near x = 0 is a property of CasADi that this container cannot
+// check (DESIGN.md "deviations" 1).  The oracle -- test infrastructure -- can evaluate the candidates so that the real
+// reference's vectors decide (tests/reconcile_constants.py); the kernels implement mode 0.  mrfo_set_attractor_norm:
+//   0  build convention: r = sqrt(x.x), gradient of the potential defined as 0 at r == 0
+//   1  regularised norm: r = sqrt(x.x + eps) everywhere (gradient x / r, finite)
+//   2  CasADi as recalled: a 1-D norm_2 is simplified to |x| (sqrt(sq(x)) -> fabs), derivative sign(x) = 0 at 0; a 3-D one
+//      keeps x / sqrt(x.x) = 0/0 = NaN at exactly x == 0.  Equal to mode 0 wherever mode 0 is defined by more than convention.
+//   3  no simplification: x / sqrt(x.x) in every dimension, NaN at exactly x == 0 (what DESIGN r1-r4 assumed of the reference)
+int g_attr_norm_mode = 0;
+double g_attr_norm_eps = 0.0;
+
+double attractor_norm(const double* x, int d) {
+  double r = 0;
+  for (int i = 0; i < d; ++i) r += x[i] * x[i];
+  return std::sqrt(g_attr_norm_mode == 1 ? r + g_attr_norm_eps : r);
+}
+
 // attractor leaf on a task x (dim d) with Jacobian J and curvature term c
 void attractor_leaf(const mrf_config& cfg, QSpec& S, int n, int d, const double* x, const double J[3][DOF_MAX],
                     const double* c, double w) {
-  double r = 0;
-  for (int i = 0; i < d; ++i) r += x[i] * x[i];
-  r = std::sqrt(r);
+  const double r = attractor_norm(x, d);
   double A = (cfg.attr_mu - cfg.attr_ml) * std::exp(-(cfg.attr_a * r) * (cfg.attr_a * r)) + cfg.attr_ml;
   double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   double f[3] = {0, 0, 0};
   for (int i = 0; i < d; ++i) {
     M[i][i] = 2.0 * A;  // L = xdot^T A xdot
-    double grad = r > 0 ? w * cfg.attr_k * std::tanh(cfg.attr_alpha * r) * x[i] / r : 0.0;  // build convention at r == 0
+    const double gain = w * cfg.attr_k * std::tanh(cfg.attr_alpha * r);
+    double grad;
+    if (g_attr_norm_mode == 0)
+      grad = r > 0 ? gain * x[i] / r : 0.0;  // build convention at r == 0
+    else if (g_attr_norm_mode == 2 && d == 1)
+      grad = gain * ((x[i] > 0) - (x[i] < 0));
+    else
+      grad = gain * (x[i] / r);              // 0/0 = NaN at x == 0 unless regularised
     f[i] = M[i][i] * grad;
   }
   pull_add(S, n, d, M, f, J, c);
@@ -399,7 +421,7 @@ void solve_fabric(const mrf_config& cfg, int robot, const Row& row, const std::v
       c0[i] = cfg.jdot_sign * K8.jdqd[i];
       x_psi_norm += x0[i] * x0[i];
     }
-    x_psi_norm = std::sqrt(x_psi_norm);
+    x_psi_norm = std::sqrt(g_attr_norm_mode == 1 ? x_psi_norm + g_attr_norm_eps : x_psi_norm);
     attractor_leaf(cfg, forced, n, d0, x0, K8.J, c0, row.prm[MRF_P_WEIGHT_GOAL_0]);
     if (cfg.n_goals > 1) {  // R (p_hand - p_link7) - x_goal_1
       PointKin K7;
@@ -487,6 +509,12 @@ void robot_spheres(const mrf_config& cfg, int robot, const double* q, const doub
 }  // namespace
 
 extern "C" {
+
+// candidate behaviours of ca.norm_2 in the attractor strings (see g_attr_norm_mode); process-wide, tests only
+void mrfo_set_attractor_norm(int mode, double eps) {
+  g_attr_norm_mode = mode;
+  g_attr_norm_eps = eps;
+}
 
 // threads used by the batch loops below (one scenario / row per thread); returns the previous maximum
 int mrfo_set_threads(int n) {

@@ -132,3 +132,13 @@ def rollout_cartesian(cfg, q0, qdot0, params, ox0, ov, oa, orad, traj=False, n_s
 def set_threads(n):
     """Threads for the oracle's batch loops (OpenMP, one scenario/row per thread); returns the previous max."""
     return lib().mrfo_set_threads(C.c_int(int(n)))
+
+
+def set_attractor_norm(mode=0, eps=0.0):
+    """Candidate behaviours of ca.norm_2 at x = 0 in the attractor strings (oracle/mrf_oracle.cpp g_attr_norm_mode):
+    0 build convention (gradient 0 at 0), 1 sqrt(x.x + eps), 2 CasADi as recalled (|x| for a 1-D task, 0/0 for 3-D),
+    3 x / sqrt(x.x) in every dimension.  Process-wide; the kernels implement mode 0."""
+    f = lib().mrfo_set_attractor_norm
+    f.argtypes = [C.c_int, C.c_double]
+    f.restype = None
+    f(int(mode), float(eps))

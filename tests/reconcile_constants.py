@@ -14,11 +14,18 @@ prints, per field, default -> fitted value, the relative change, and whether the
     stage M_e = I (a factor 1/(1+eps) on h_g and h_f -- an O(1e-6) relative effect, i.e. exactly the pin test's
     tolerance: a first-contact miss of that size is this convention, not a wrong constant), eps missing from the
     energization denominators, and the unregularised inverse;
+  * the behaviour of ca.norm_2 in the attractor strings at / near x = 0 is enumerated through the oracle's
+    mrfo_set_attractor_norm (norm_variants below): the build convention (gradient 0 at 0), CasADi as recalled (|x| with
+    derivative sign(x) for a 1-D task, 0/0 for a 3-D one), x/sqrt(x.x) in every dimension (NaN at 0 -- what DESIGN r1-r4
+    assumed of the reference although its own start pose has q[6] == x_goal_2, PM:93 / EXJ:428: the committed case "rest"
+    sits exactly there and decides), and regularised norms sqrt(x.x + eps).  NaN patterns are compared as patterns;
   * continuous constants are fitted by least squares (scipy) on multiplicative factors, starting from the defaults:
     base_mass, eps, attractor (k, alpha, mu, ml, a), damper beta (a, r, b, s) and eta (a, s), and the k of the
     limit-geometry, limit-Finsler and plane-Finsler strings.
 Outcome "residual <= 1e-6 at the defaults" = the recalled specification is the reference's.  Otherwise the printed
-overrides are what `planner.constants` / `config.set_strings` must be given (no kernel change: DESIGN.md section 2).
+overrides are what `planner.constants` / `config.set_strings` must be given (no kernel change: DESIGN.md section 2) --
+or, zero-code:  python tests/reconcile_constants.py --write multi-robot-fabrics_amd/constants.json  writes them where
+config.py picks them up for every planner built afterwards ($MRF_CONSTANTS names another path).
 It lives under tests/ because it drives the oracle (only tests may)."""
 import itertools
 import os
@@ -135,7 +142,51 @@ def composition_variants(want_actions):
     return out
 
 
+NORM_VARIANTS = [("build convention: gradient 0 at x = 0", 0, 0.0),
+                 ("CasADi as recalled: |x| (derivative sign x) in 1-D, x/sqrt(x.x) in 3-D", 2, 0.0),
+                 ("x / sqrt(x.x) in every dimension: NaN at x = 0", 3, 0.0),
+                 ("sqrt(x.x + 1e-12)", 1, 1e-12), ("sqrt(x.x + 1e-8)", 1, 1e-8), ("sqrt(x.x + 1e-6)", 1, 1e-6)]
+
+
+def norm_variants(want_actions):
+    """Panda single-step cases under each candidate behaviour of ca.norm_2 in the attractor strings ->
+    {label: (max relative residual over the entries finite on both sides, NaN patterns equal?)}."""
+    out = {}
+    try:
+        for label, mode, eps in NORM_VARIANTS:
+            oracle_lib.set_attractor_norm(mode, eps)
+            got = rc.oracle_actions(oracle_lib, rc.panda_action_cases())
+            same_nan = bool(np.array_equal(np.isnan(got), np.isnan(want_actions)))
+            both = np.isfinite(got) & np.isfinite(want_actions)
+            scale = max(1e-300, float(np.abs(want_actions[both]).max())) if both.any() else 1.0
+            err = float(np.abs(got[both] - want_actions[both]).max() / scale) if both.any() else float("nan")
+            out[label] = (err, same_nan)
+    finally:
+        oracle_lib.set_attractor_norm(0, 0.0)
+    return out
+
+
+def write_constants(path, base, names, theta, discrete, residual, source):
+    """The fitted conventions and constants as the JSON file config.py loads ($MRF_CONSTANTS / constants.json)."""
+    import json
+    fields = {k: v for k, v in discrete["fields"].items()}
+    for n, t in zip(names, theta):
+        if not n.endswith(".k"):
+            fields[n] = base[n] * t * discrete.get("scale", {}).get(n, 1.0)
+    strings = dict(discrete["strings"])
+    leaf_scaled = {n[:-2]: t for n, t in zip(names, theta) if n.endswith(".k") and abs(t - 1) > 1e-9}
+    doc = {"_meta": {"written_by": "tests/reconcile_constants.py --write", "fitted_against": source,
+                     "max_relative_residual": residual, "conventions": discrete["label"],
+                     "unapplied_leaf_gain_factors": leaf_scaled or None},
+           "fields": fields, "strings": strings}
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+        f.write("\n")
+    print(f"wrote {path}" + (f"  (leaf gain factors {leaf_scaled} need the strings edited by hand)" if leaf_scaled else ""))
+
+
 def main():
+    write_to = sys.argv[sys.argv.index("--write") + 1] if "--write" in sys.argv else None
     want = {}
     for kind in ("panda_actions", "planar_actions", "panda_rollout"):
         if rc.have(kind):
@@ -145,6 +196,8 @@ def main():
         got = rc.oracle_actions(oracle_lib, rc.panda_action_cases())
         for label, err in composition_variants(got).items():
             print(f"  {err:10.3e}  {label}")
+        for label, (err, same) in norm_variants(got).items():
+            print(f"  {err:10.3e}  NaN pattern {'same' if same else 'DIFFERS'}  {label}")
         return 0
     if not want:
         print(rc.HOW)
@@ -170,15 +223,24 @@ def main():
         for label, err in composition_variants(want["panda_actions"]).items():
             print(f"  {err:10.3e}  {label}")
         print()
+        print("behaviour of ca.norm_2 in the attractor strings (max relative residual on finite entries; NaN pattern):")
+        for label, (err, same) in norm_variants(want["panda_actions"]).items():
+            print(f"  {err:10.3e}  NaN pattern {'same' if same else 'DIFFERS'}  {label}")
+        print("  (only the first convention is what the kernels implement: anything else winning here needs a code change)\n")
     print("discrete conventions at the default constants (max relative residual; the first line is the build's default):")
     for err, d, _ in combos[:1] + sorted(combos[1:], key=lambda c: c[0])[:5]:
         print(f"  {err:10.3e}  {d['label']}")
+    source = sorted(os.path.basename(rc.FILES[k]) for k in want)
     if combos[0][0] <= 1e-6:
         print("\nRESULT: the recalled specification reproduces the reference at the default constants (<= 1e-6).")
+        if write_to:
+            write_constants(write_to, base, names, np.ones(len(names)), combos[0][1], combos[0][0], source)
         return 0
     exact = [c for c in combos if c[0] <= 1e-6]
     if exact:
         print("\nRESULT: the default CONSTANTS reproduce the reference with these discrete conventions:\n  " + exact[0][1]["label"])
+        if write_to:
+            write_constants(write_to, base, names, np.ones(len(names)), exact[0][1], exact[0][0], source)
         return 0
     # no convention fits at the default constants: fit the continuous ones under every convention (the default first,
     # so that it wins ties) and keep the convention with the smallest residual
@@ -198,8 +260,10 @@ def main():
         ident = "yes" if s > 1e-6 else "no (flat)"
         flag = "  <-- differs" if (abs(t - 1) > 1e-3 and s > 1e-6) else ""     # the bounded fit resolves ~1e-4
         print(f"{n:22s} {base[n]:14.8g} {base[n] * t:14.8g} {t - 1:11.2e}  {ident}{flag}")
-    print("\napply with planner.constants[...] (scalar fields) / config.set_strings (strings); re-run "
-          "tests/test_reference_pin.py afterwards.")
+    if write_to:
+        write_constants(write_to, base, names, fit.x, best, float(np.abs(fit.fun).max()), source)
+    print("\napply with planner.constants[...] (scalar fields) / config.set_strings (strings), or re-run with "
+          "--write multi-robot-fabrics_amd/constants.json; then tests/test_reference_pin.py.")
     return 0 if np.abs(fit.fun).max() <= 1e-6 else 1
 
 

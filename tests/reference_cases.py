@@ -12,7 +12,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KINDS = ("panda_actions", "planar_actions", "panda_rollout", "panda_rollout_c4", "panda_cartesian")
 FILES = {k: os.path.join(GOLD, f"reference_{k}.npz") for k in KINDS}
 HOW = ("parity with the CasADi path is UNPINNED: tests/golden/reference_*.npz are absent.  Generate them where the "
-       "reference runs (python 3.9 + tests/golden/reference_env.txt): python tests/golden/make_reference_golden.py")
+       "reference runs (python 3.9 + tests/golden/reference_requirements.txt): python tests/golden/make_reference_golden.py")
 
 
 def have(kind):

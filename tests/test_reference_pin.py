@@ -169,6 +169,57 @@ def test_composition_conventions_are_diagnosable(oracle):
     assert all(1e-9 < v[k] < 1e-4 for k in labels[2:])
 
 
+def test_attractor_norm_conventions_are_diagnosable(oracle):
+    """How ca.norm_2 of the attractor strings behaves at x = 0 cannot be checked here; the committed case "rest" sits
+    exactly on it (q[6] == x_goal_2, the reference's own start pose PM:93 / EXJ:428), so the reference's vector for that
+    case decides between the candidates reconcile_constants.py enumerates: the build convention and CasADi-as-recalled
+    agree to round-off, "x / sqrt(x.x) in every dimension" turns that one case into NaN (a different NaN pattern), and a
+    regularised norm moves finite digits only."""
+    import reconcile_constants as recon
+    cases = rc.panda_action_cases()
+    rest = [i for i, c in enumerate(cases) if c[0] == "rest"]
+    assert len(rest) == 1 and float(cases[rest[0]][2][6, 0] - cases[rest[0]][4][17, 0]) == 0.0     # q[6] - x_goal_2
+    got = rc.oracle_actions(oracle, cases)
+    assert np.isfinite(got).all()
+    v = recon.norm_variants(got)
+    labels = list(v)
+    assert v[labels[0]] == (0.0, True)
+    assert v[labels[1]][0] < 1e-15 and v[labels[1]][1]                 # |x| with sign(0) = 0: the same numbers
+    assert not v[labels[2]][1]                                        # 0/0 in 1-D: the "rest" case becomes NaN
+    assert all(v[k][1] and v[k][0] < 1e-8 for k in labels[3:])         # regularised norms: far below the pin tolerance
+    oracle.set_attractor_norm(3, 0.0)
+    try:
+        bad = rc.oracle_actions(oracle, cases)
+    finally:
+        oracle.set_attractor_norm(0, 0.0)
+    assert [i for i in range(len(cases)) if not np.isfinite(bad[i]).all()] == rest
+
+
+def test_reconciliation_writes_constants_that_config_loads(oracle, tmp_path, monkeypatch):
+    """Zero-code reconciliation: stand-in "reference" vectors made by the oracle with another discrete
+    convention (attractor metric M = A instead of the Hessian 2A) -> reconcile_constants.py --write finds the convention and
+    writes the JSON file -> every planner configuration built afterwards carries it ($MRF_CONSTANTS), and the oracle on
+    that configuration reproduces the stand-in vectors."""
+    import sys
+    import reconcile_constants as recon
+    from multi_robot_fabrics_amd import config
+    truth = {"attr_mu": 1.0, "attr_ml": 0.15}            # M = A: both metric constants halved
+    files = {k: str(tmp_path / f"reference_{k}.npz") for k in rc.KINDS}
+    acts = rc.oracle_actions(oracle, rc.panda_action_cases(truth))
+    np.savez(files["panda_actions"], action=acts)
+    monkeypatch.setattr(rc, "FILES", files)
+    out = str(tmp_path / "constants.json")
+    monkeypatch.setattr(sys, "argv", ["reconcile_constants.py", "--write", out])
+    assert recon.main() == 0
+    monkeypatch.setenv("MRF_CONSTANTS", out)
+    cfg = config.panda_config(n_robots=1, horizon=1)
+    assert cfg.attr_mu == 1.0 and cfg.attr_ml == 0.15 and cfg.jdot_sign == -1.0
+    again = rc.oracle_actions(oracle, rc.panda_action_cases())          # built through config.panda_config: reconciled
+    assert rel(again, acts) < 1e-12
+    monkeypatch.delenv("MRF_CONSTANTS")
+    assert config.panda_config(n_robots=1, horizon=1).attr_mu == 2.0
+
+
 @pytest.mark.gpu
 def test_reference_recipe_dry_run_on_the_mirrors(tmp_path):
     """tests/golden/make_reference_golden.py cannot run where the reference's wheels are missing -- but its plumbing

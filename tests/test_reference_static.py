@@ -128,3 +128,23 @@ def test_load_yaml_settings_reads_the_reference_yaml(tmp_path):
     assert p.ROLLOUT_FABRICS is True and p.ROLLOUTS_PLOTTING is False and p.ESTIMATE_GOAL is False
     assert p.STATIC_OR_DYN_FABRICS == 1 and p.RESOLVE_DEADLOCKS == 1
     assert p.nr_obsts_dyn_all == [8 * 4] * 2 and p.nr_obsts_dyn == [8] * 2
+
+
+def test_reference_requirements_are_the_lock_file():
+    """tests/golden/reference_requirements.txt (the environment of the pin recipe) is generated, not typed: it equals what
+    make_reference_requirements.py renders from the reference's poetry.lock, and names the three packages that hold the
+    arithmetic at the versions SURVEY 8c cites."""
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "reference_requirements.txt")) as f:
+        text = f.read()
+    for pin in ("casadi==3.5.5", "fabrics==0.9.5", "forwardkinematics==1.2.3"):
+        assert pin + " \\\n" in text, pin
+    assert text.count("--hash=sha256:") > 300
+    lock = "/root/reference/poetry.lock"
+    if not os.path.exists(lock):
+        pytest.skip("the reference is not present here")
+    sys.path.insert(0, here)
+    import make_reference_requirements as gen
+    assert gen.render(lock) == text

@@ -6,9 +6,9 @@
 tag=${1:-rXX}; dt=${2:-f64}
 root=$(pwd); out=$root/gpurun_out/cpmc_$tag
 mkdir -p $out $root/gpurun_out/profiles; cd /tmp; export TMPDIR=/tmp
-# CART32 stays out of the counter passes: it launches the same k_rollout_cart_panda instantiation as CART on another grid, and
-# the summary is keyed by kernel name (its roofline entry is the formulation-equivalent byte rate only)
-cfgs="C2 C3 C5 CART CARTC CARTC32"
+# CART32 / CARTC32 stay out of the counter passes: they launch the same k_rollout_cart_panda instantiation as CART on another
+# grid, and the summary is keyed by kernel name (their roofline entries are the formulation-equivalent byte rate only)
+cfgs="C2 C3 C5 CART CARTC"
 python3 $root/tools/prof_configs.py $dt $cfgs > $out/prof_configs.txt 2>&1
 specs=""
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64" "SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SMEM SQ_INSTS_VMEM" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
@@ -26,5 +26,4 @@ python3 $root/tools/make_traffic.py $pmc config_C3_${dt}_B$(size C3) --horizon 2
 python3 $root/tools/make_traffic.py $pmc config_C5_${dt}_B$(size C5) --horizon 50 --kernel-substring "k_rollout_panda<double, LS_reference, false>" --out $tj >> $out/summary.log 2>&1
 python3 $root/tools/make_traffic.py $pmc config_CART_${dt}_B$(size CART) --horizon 30 --kernel-substring "k_rollout_cart_panda<" --out $tj >> $out/summary.log 2>&1
 python3 $root/tools/make_traffic.py $pmc config_CARTC_${dt}_B$(size CARTC) --horizon 30 --kernel-substring "k_rollout_cartc_panda<double, LS_reference, 0>" --out $tj >> $out/summary.log 2>&1
-python3 $root/tools/make_traffic.py $pmc config_CARTC32_${dt}_B$(size CARTC32) --horizon 30 --kernel-substring "k_rollout_cartc_panda<double, LS_reference, 2>" --out $tj >> $out/summary.log 2>&1
 tail -c 2500 $out/summary.log; cat $out/prof_configs.txt | cut -c1-400
