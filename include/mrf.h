@@ -144,6 +144,10 @@ int mrf_create(const mrf_config* cfg, int32_t device_id, mrf_handle** out);
 void mrf_destroy(mrf_handle* h);
 const char* mrf_last_error(const mrf_handle* h);
 int mrf_abi_version(void);
+/* 1 when the library carries the float32 instantiations of the kernels (built with -DMRF_WITH_F32), else 0: mrf_create
+ * then refuses cfg.scalar = MRF_F32 with MRF_E_CONFIG.  The default build is float64 only -- the reference's arithmetic
+ * (CasADi SX / DM); float32 is a throughput option for well-separated robots (accuracy: DESIGN.md section 3). */
+int mrf_build_has_f32(void);
 int64_t mrf_config_sizeof(void); /* sizeof(mrf_config) as compiled, for FFI layout checks */
 
 /* Replaces ParameterizedFabricPlanner.compute_action (EXJ:441,444; EXC:447,449; FPC:150-190).

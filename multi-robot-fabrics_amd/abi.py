@@ -76,7 +76,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
 
 EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
-    "mrf_abi_version", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
+    "mrf_abi_version", "mrf_build_has_f32", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
     "mrf_fk_spheres", "mrf_rollout_sphere_traj", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
@@ -154,6 +154,9 @@ def load_library(path=None):
     lib.mrf_last_error.restype = C.c_char_p
     lib.mrf_abi_version.argtypes = []
     lib.mrf_abi_version.restype = C.c_int
+    if hasattr(lib, "mrf_build_has_f32"):      # absent in older builds under A/B timing (MRF_HIP_LIB + MRF_ABI_ANY)
+        lib.mrf_build_has_f32.argtypes = []
+        lib.mrf_build_has_f32.restype = C.c_int
     lib.mrf_config_sizeof.argtypes = []
     lib.mrf_config_sizeof.restype = C.c_int64
     lib.mrf_compute_action.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -258,3 +261,9 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def has_f32():
+    """True when the loaded library carries the float32 kernels (built with -DMRF_WITH_F32; the default build does not)."""
+    lib = load_library()
+    return bool(lib.mrf_build_has_f32()) if hasattr(lib, "mrf_build_has_f32") else True

@@ -93,13 +93,17 @@ int launch(mrf_handle* h, K kernel, dim3 grid, dim3 block, hipStream_t st, Args.
   return check_hip(h, hipGetLastError(), "kernel launch");
 }
 
+// -DMRF_WITH_F32: the float32 instantiations of every kernel are compiled as well.  Not in the default build (r5): they are
+// 5-15 % faster than float64 at one wave per SIMD, accurate to 1e-3 on rollouts and unusable below a barrier coordinate of
+// ~0.1, and they double the compile time; mrf_create refuses scalar = MRF_F32 without them
+// (mrf_build_has_f32()).
 // -DMRF_DEV_F64_PANDA_ONLY (development builds, tools/build_variant.sh): only the float64 / reference-leaf-set
 // instantiations are compiled (a quarter of the compile time when iterating on one kernel's ISA); any other
 // configuration then fails loudly instead of running.
 template <typename F>
 int dispatch_scalar(mrf_handle* h, F f) {
-#ifdef MRF_DEV_F64_PANDA_ONLY
-  if (h->cfg.scalar != MRF_F64) return fail(h, MRF_E_CONFIG, "development build: float64 only");
+#if defined(MRF_DEV_F64_PANDA_ONLY) || !defined(MRF_WITH_F32)
+  if (h->cfg.scalar != MRF_F64) return fail(h, MRF_E_CONFIG, "this build has no float32 kernels (build with -DMRF_WITH_F32)");
   return f(double{});
 #else
   return h->cfg.scalar == MRF_F64 ? f(double{}) : f(float{});
@@ -144,7 +148,11 @@ int dispatch(mrf_handle* h, F f) {  // f(scalar tag, leaf-set tag)
   return f(double{}, LeafSetPanda{});
 #else
   if (h->cfg.scalar == MRF_F64) return fast ? f(double{}, LeafSetPanda{}) : f(double{}, LeafSetGeneric{});
+#ifdef MRF_WITH_F32
   return fast ? f(float{}, LeafSetPanda{}) : f(float{}, LeafSetGeneric{});
+#else
+  return fail(h, MRF_E_CONFIG, "this build has no float32 kernels (build with -DMRF_WITH_F32)");
+#endif
 #endif
 }
 

@@ -1645,6 +1645,9 @@ std::string validate(const mrf_config& c) {
   if (c.abi_version != MRF_ABI_VERSION) return "abi_version mismatch";
   if (c.model != MRF_MODEL_PANDA7 && c.model != MRF_MODEL_PLANAR3) return "unknown model";
   if (c.scalar != MRF_F64 && c.scalar != MRF_F32) return "unknown scalar type";
+#ifndef MRF_WITH_F32
+  if (c.scalar == MRF_F32) return "this build has no float32 kernels (build with -DMRF_WITH_F32; mrf_build_has_f32())";
+#endif
   if (c.mode != MRF_MODE_ACC && c.mode != MRF_MODE_VEL) return "unknown mode";
   if (c.n_robots < 1 || c.n_robots > MRF_MAX_ROBOTS) return "n_robots out of range";
   if (c.n_spheres < 0 || c.n_spheres > MRF_MAX_SPHERES) return "n_spheres out of range";
@@ -1776,6 +1779,14 @@ int mrf_host::rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* 
 extern "C" {
 
 int mrf_abi_version(void) { return MRF_ABI_VERSION; }
+
+int mrf_build_has_f32(void) {
+#ifdef MRF_WITH_F32
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 #ifdef MRF_COOP_CLOCKS
 int mrf_debug_clocks(long long* out, int n) {

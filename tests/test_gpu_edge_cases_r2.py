@@ -105,9 +105,14 @@ def test_rollout_cartesian_coupled_edge_cases():
     want = h.rollout_cartesian_coupled(q, qd, prm)
     cfg32 = cfg.copy()
     cfg32.scalar = abi.F32
-    h32 = FabricHandle(cfg32, 0)
-    got = h32.rollout_cartesian_coupled(*(h32.tensor(batch[k]) for k in ("q", "qdot", "params")))
-    assert torch.allclose(got.double(), want, rtol=2e-3, atol=1e-5)
+    if abi.has_f32():
+        h32 = FabricHandle(cfg32, 0)
+        got = h32.rollout_cartesian_coupled(*(h32.tensor(batch[k]) for k in ("q", "qdot", "params")))
+        assert torch.allclose(got.double(), want, rtol=2e-3, atol=1e-5)
+    else:                                   # the default build: float64 only, and it says so
+        from multi_robot_fabrics_amd.runtime import MrfError
+        with pytest.raises(MrfError, match="float32"):
+            FabricHandle(cfg32, 0)
 
 
 def abi_status(name):

@@ -54,7 +54,7 @@ def test_error_vs_min_barrier_coordinate(oracle):
     want_qdd, want = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
     table = {"bins": BINS, "rows": []}
     errs = {}
-    for name, scalar in (("f64", abi.F64), ("f32", abi.F32)):
+    for name, scalar in (("f64", abi.F64), ("f32", abi.F32))[:2 if abi.has_f32() else 1]:
         c = cfg.copy()
         c.scalar = scalar
         h = FabricHandle(c, 0)
@@ -67,11 +67,12 @@ def test_error_vs_min_barrier_coordinate(oracle):
     for lo, hi in zip(BINS[:-1], BINS[1:]):
         sel = (xm >= lo) & (xm < hi)
         row = {"x_min_range": [lo, hi], "scenarios": int(sel.sum())}
-        for name in ("f64", "f32"):
+        for name in errs:
             row[name] = {"max_rel_err": float(errs[name][sel].max()), "median_rel_err": float(np.median(errs[name][sel]))}
         table["rows"].append(row)
         assert row["f64"]["max_rel_err"] < F64_BOUND[lo], row
-        assert row["f32"]["max_rel_err"] < F32_BOUND[lo], row
+        if "f32" in errs:               # the default build has no float32 kernels (abi.has_f32())
+            assert row["f32"]["max_rel_err"] < F32_BOUND[lo], row
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "error_vs_barrier.json"), "w") as f:

@@ -325,7 +325,7 @@ def test_host_buffer_entry_points_equal_the_device_ones():
     points on the same inputs: identical kernels, so bit-identical results; f32 handles convert while packing."""
     import torch
     from multi_robot_fabrics_amd.runtime import FabricHandle
-    for scalar, exact in ((abi.F64, True), (abi.F32, False)):
+    for scalar, exact in ((abi.F64, True), (abi.F32, False))[:2 if abi.has_f32() else 1]:
         cfg = config.panda_config(n_robots=3, horizon=4, scalar=scalar)
         cfg.goal_estimate_mask = 0b110
         b = scenarios.panda_batch(cfg, 5, seed=9)

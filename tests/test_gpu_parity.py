@@ -253,6 +253,7 @@ def test_rollout_cartesian_coupled(oracle, n_robots, per_link, dynamic, kernel):
     assert torch.equal(h.rollout_cartesian_coupled(t(batch["q"]), t(batch["qdot"]), t(batch["params"])), avg)
 
 
+@pytest.mark.skipif(not abi.has_f32(), reason="library built without float32 kernels (MRF_WITH_F32)")
 @pytest.mark.parametrize("per_link", [0, 1])
 def test_rollout_cartesian_coupled_float32_tile(oracle, per_link):
     """The LDS-tile form of the coupled Cartesian rollout in float32 (link-origin table and one offset sphere per link)

@@ -15,6 +15,7 @@ fi
 # same per-file flags as __graft_entry__.build(): the solve kernels with -ffast-math, the control-step unit without
 tmp=$(mktemp -d)
 hip="/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC"
+[ "$MRF_WITH_F32" = "1" ] && hip="$hip -DMRF_WITH_F32"
 $hip ${KERNEL_FLAGS--ffast-math} "$@" -c -o $tmp/k.o "$src/multi-robot-fabrics_amd/csrc/mrf_kernels.hip" &
 objs="$tmp/k.o"
 if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_rollout_wp.hip" ]; then
