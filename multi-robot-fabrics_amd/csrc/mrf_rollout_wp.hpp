@@ -62,24 +62,31 @@ __device__ __forceinline__ void wp_fold(const DevCfg<T>& cfg, const T* __restric
   typedef const __attribute__((address_space(3))) T* lds_ptr;
   using CL = LeafPow<4, 4, MRF_GATE_NONE, MRF_GATE_NONE>;
   const T zero[3] = {T(0), T(0), T(0)};
+  // links 1 and 2 of every other robot: one point that never moves, folded once with weight 2
 #pragma unroll 1
   for (int d = 0; d + 1 < N; ++d) {
     int jr = li + 1 + d;
     if (jr >= N) jr -= N;
-    {
-      // links 1 and 2 of robot jr: one point that never moves, folded once with weight 2
-      lds_ptr s = (lds_ptr)(stat + jr * 3);
-      const T xs[3] = {s[0], s[1], s[2]};
-      accumulate_obstacle<CL>(cfg, E, xs, zero, zero, ((lds_ptr)rad)[0], false, acc, T(2));
-    }
+    lds_ptr s = (lds_ptr)(stat + jr * 3);
+    const T xs[3] = {s[0], s[1], s[2]};
+    accumulate_obstacle<CL>(cfg, E, xs, zero, zero, ((lds_ptr)rad)[0], false, acc, T(2));
+  }
+  // the five moving link origins of every other robot: one flat loop over (robot, slot), all ten operands of a sphere
+  // requested at the top of its iteration (volatile: in program order).  Fetching the NEXT sphere before folding the
+  // current one (the row kernel's depth-one pipeline) needs 20 more registers here and was measured slower: 212 B of scratch
+  // per lane, 3.72 against 3.43 ms (profiles/r05_wp_pmc.json "_meta").
 #pragma unroll 1
-    for (int slot = 0; slot < 5; ++slot) {
-      lds_ptr src = (lds_ptr)(tile + slot * 9 * 64 + ls * N + jr);
-      T buf[9];
+  for (int m = 0; m < 5 * (N - 1); ++m) {
+    const int d = m / 5, slot = m - 5 * d;
+    int jr = li + 1 + d;
+    if (jr >= N) jr -= N;
+    typedef const volatile __attribute__((address_space(3))) T* lds_vptr;
+    lds_vptr src = (lds_vptr)(tile + slot * 9 * 64 + ls * N + jr);
+    T buf[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) buf[k] = src[k * 64];
-      accumulate_obstacle<CL>(cfg, E, buf, buf + 3, buf + 6, ((lds_ptr)rad)[1 + slot], false, acc, slot == 2 ? T(2) : T(1));
-    }
+    for (int k = 0; k < 9; ++k) buf[k] = src[k * 64];
+    const T ro = ((lds_vptr)rad)[1 + slot];
+    accumulate_obstacle<CL>(cfg, E, buf, buf + 3, buf + 6, ro, false, acc, slot == 2 ? T(2) : T(1));
   }
 }
 
