@@ -10,8 +10,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "multi-robot-fabrics_amd", "csrc", "mrf_kernels.hip")
-ASM = os.environ.get("MRF_ASM", "/tmp/mrf_kernels.s")
+# MRF_SRC=mrf_rollout_wp.hip selects the wave-pair kernel's translation unit (its phase markers are the WP_STAMP points)
+SRC = os.path.join(ROOT, "multi-robot-fabrics_amd", "csrc", os.environ.get("MRF_SRC", "mrf_kernels.hip"))
+ASM = os.environ.get("MRF_ASM", "/tmp/" + os.path.basename(SRC).replace(".hip", ".s"))
 
 
 def classify(op):
@@ -42,7 +43,8 @@ def classify(op):
 
 def main():
     if not os.path.exists(ASM) or os.path.getmtime(ASM) < max(
-            os.path.getmtime(SRC), os.path.getmtime(os.path.join(os.path.dirname(SRC), "mrf_device.hpp"))):
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(os.path.dirname(SRC), "mrf_device.hpp")),
+            os.path.getmtime(os.path.join(os.path.dirname(SRC), "mrf_rollout_wp.hpp"))):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17",
                                "-ffast-math", "--cuda-device-only", "-S", "-DMRF_ISA_MARKS", "-o", ASM, SRC], stderr=subprocess.DEVNULL)
     lines = open(ASM).read().split("\n")
