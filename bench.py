@@ -207,13 +207,16 @@ def parity_spot_check(cfg_roll, cfg_act, batch, avg, act, n_scen=64, tol=1e-9):
             "against": "oracle/mrf_oracle.cpp (float64 CPU restatement) on the first scenarios of the timed batch"}
 
 
-def _traffic_entry(prefix):
-    """(exact-or-latest entry of profiles/traffic.json whose key starts with `prefix`, its key)."""
+def _traffic_entry(prefix, exact=None):
+    """(entry of profiles/traffic.json, its key): the key `exact` when present, else the last one that starts with `prefix`
+    (counters taken at another batch size: flops per unit still hold, bytes per launch do not)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, None
     with open(tpath) as f:
         tj = json.load(f)
+    if exact and isinstance(tj.get(exact), dict):
+        return tj[exact], exact
     keys = [k for k in sorted(tj) if k.startswith(prefix) and isinstance(tj[k], dict)]
     return (tj[keys[-1]], keys[-1]) if keys else (None, None)
 
@@ -285,7 +288,7 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
     alg = units * bytes_unit / (ms * 1e-3)
     roof = {"hbm_algorithmic": {"achieved": alg / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / HBM_PEAK,
                                 "bytes_per_unit": bytes_unit}}
-    src, key = _traffic_entry(f"config_{name}_{dtype}_")
+    src, key = _traffic_entry(f"config_{name}_{dtype}_", exact=f"config_{name}_{dtype}_B{B}")
     if src is not None and "flops_per_unit" in src:
         tf = units * src["flops_per_unit"] / (ms * 1e-3) / 1e12
         roof.update(bound="valu_" + dtype, achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf,
