@@ -52,6 +52,8 @@ def draw_seed(seed):
     cfg = config.panda_config(n_robots=N, horizon=int(rng.integers(2, 9)), dynamic=int(rng.integers(0, 2)))
     cfg.goal_estimate_mask = int(rng.integers(0, 1 << N))
     cfg.kernel_select = int(rng.integers(0, 3))
+    if os.environ.get("MRF_SOAK_KERNEL"):      # e.g. 3: the wave-pair rollout wherever it applies (the draw above stays in
+        cfg.kernel_select = int(os.environ["MRF_SOAK_KERNEL"])   # the stream, so the scenarios equal the recorded runs')
     if rng.random() < 0.4:
         cfg.ego_link_mask = int(rng.integers(1, 64))
     if rng.random() < 0.4:
