@@ -159,6 +159,33 @@ def test_rollout_jointspace(oracle, scalar, n_robots, horizon, n_scen, mask, dyn
         assert np.allclose(avg, want_avg, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("n_goals,n_planes,use_limits,dynamic,n_robots", [(0, 1, 1, 1, 3), (1, 1, 1, 1, 2), (2, 0, 1, 1, 3),
+                                                                          (3, 1, 0, 0, 4), (3, 0, 0, 1, 2), (3, 1, 1, 1, 5)])
+def test_rollout_wave_pair_planner_switches(oracle, n_goals, n_planes, use_limits, dynamic, n_robots):
+    """k_rollout_panda_wp (kernel_select = 3) splits the solve over two waves: attractors, plane leaves, joint limits and the
+    no-goal composition (h_g handed to the other wave) each live in one of them -- every planner switch, robot counts with
+    idle tail lanes (3, 5) and a ragged last workgroup, against the oracle and bit-for-bit repeatable."""
+    cfg = config.panda_config(n_robots=n_robots, horizon=6, dynamic=dynamic)
+    cfg.n_goals, cfg.n_planes, cfg.use_limits = n_goals, n_planes, use_limits
+    cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1 if n_goals else 0
+    cfg.kernel_select = 3
+    n_scen = 2 * (64 // n_robots) + 5
+    batch = scenarios.panda_batch(cfg, n_scen, seed=31 + n_goals, x_min=0.1 if n_robots < 4 else 0.2,
+                                  q_spread=0.3 if n_robots < 4 else 0.15)
+    want_avg, want_q, want_qd = oracle.rollout(cfg, batch["q"], batch["qdot"], batch["params"], traj=True)
+    h = FabricHandle(cfg, 0)
+    t = h.tensor
+    avg, tq, tqd = h.rollout(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), want_traj=True)
+    assert relerr(tqd.cpu().numpy(), want_qd) < F64_RTOL and relerr(tq.cpu().numpy(), want_q) < F64_RTOL
+    assert relerr(avg.cpu().numpy(), want_avg) < F64_RTOL
+    assert torch.equal(h.rollout(t(batch["q"]), t(batch["qdot"]), t(batch["params"])), avg)
+    # the row kernel on the same inputs: the same numbers to round-off (another summation order)
+    c1 = cfg.copy()
+    c1.kernel_select = 1
+    avg1 = FabricHandle(c1, 0).rollout(t(batch["q"]), t(batch["qdot"]), t(batch["params"]))
+    assert relerr(avg.cpu().numpy(), avg1.cpu().numpy()) < 1e-11
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_rollout_eight_pandas(oracle, kernel):
     """BASELINE config 5 shape: 8 Pandas on the build-defined ring, 20 spheres per robot with link-local offsets."""
