@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: SQ counter passes over tools/prof_rollout.py for the kernel variant selected by MRF_ROLLOUT_WP
 # usage: tools/pmc_wp.sh <tag> [B]     -> gpurun_out/pmc_<tag>.txt  (one line per counter, per kernel)
+#        PROG="tools/prof_configs.py f64 CART32" tools/pmc_wp.sh cart32      any other launcher of rollout kernels
 tag=${1:-wp}; B=${2:-129024}
 root=$(pwd); out=$root/gpurun_out/pmcwp_$tag
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
@@ -10,7 +11,7 @@ passes=${PASSES:-"SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES;SQ_INSTS_VALU SQ_INSTS
 IFS=';' read -ra plist <<< "$passes"
 for pass in "${plist[@]}"; do
   name=$(echo $pass | tr ' ' '+')
-  timeout 120 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/$name -- python3 $root/tools/prof_rollout.py $B f64 2 > $out/$name.log 2>&1 || echo "pass $name: rc=$?"
+  timeout 180 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/$name -- python3 $root/${PROG:-tools/prof_rollout.py $B f64 2} > $out/$name.log 2>&1 || echo "pass $name: rc=$?"
 done
 python3 - $out > $root/gpurun_out/pmc_$tag.txt <<'PY'
 import csv, glob, sys, collections
