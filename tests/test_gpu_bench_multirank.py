@@ -40,6 +40,39 @@ def test_two_ranks_one_gpu_scenario_sharding():
     assert r["roofline"]["effective_clock_ghz"] == r["effective_clock_ghz"]
 
 
+def _audit_fields(roof, link_bytes):
+    """What the first run on real links is audited with: the measured HBM traffic of the transport's own
+    kernels, and the link model's prediction next to the measured step."""
+    link = roof["link"]
+    assert abs(link["predicted_ms_per_step"] - link_bytes / 153e9 * 1e3) < 1e-12
+    assert abs(link["predicted_ms_per_rollout"] - link["predicted_ms_per_step"] * link["steps"]) < 1e-9
+    assert link["measured_ms_per_step"] > 0
+    assert set(link["model"]["link_bound_above_scenarios"]) == {"peer", "rccl"} and "peer_vs_rccl" in link["model"]
+    assert roof["traffic"] is not None and roof["traffic"] > 0 and roof["traffic_key"].startswith("sharded_")
+
+
+def test_world_one_robot_sharded_block_carries_the_audit_fields():
+    """The default single-GPU run's secondary block: both transports with a group of one (no link), the measured HBM traffic
+    of their kernels and the link model's prediction for one robot per GPU at this batch."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scenarios", "2016",
+           "--no-configs", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["exit_code"] == 0
+    for transport in ("rccl", "peer"):
+        blk = r["robot_sharded"][transport]
+        assert "error" not in blk, blk
+        roof = blk["roofline"]
+        assert roof["bound"] == "hbm" and roof["link"]["bytes_per_link_per_step"] == 0
+        assert abs(roof["link"]["predicted_ms_per_step"] - 6 * 9 * 8 * 2016 / 153e9 * 1e3) < 1e-12    # one robot per GPU
+        assert roof["link"]["measured_ms_per_step"] > 0 and roof["traffic"] > 0
+        assert roof["traffic_key"] == f"sharded_{transport}_f64"
+
+
 def test_bare_launch_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher: the parent starts torch.distributed.run as a child before touching
     the GPU and relays exactly one JSON line."""
@@ -91,6 +124,7 @@ def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
     assert r["roofline"]["link"]["frac"] > 0 and r["roofline"]["hbm_algorithmic"]["frac"] > 0
     assert r["roofline"]["hbm_algorithmic"]["bytes_per_unit"] > 0
     assert r["allgather_bytes_per_rank_per_step"] == 2 * 6 * 9 * 1008 * 8
+    _audit_fields(r["roofline"], link_bytes=2 * 6 * 9 * 1008 * 8)
 
 
 def test_stuck_secondary_block_cannot_take_the_headline_with_it():
@@ -156,6 +190,7 @@ def test_four_ranks_one_gpu_one_robot_per_rank_plus_a_replica():
     assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]            # MAX over all four ranks
     assert abs(r["value"] - (504 + 168) * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
     assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 1 * 6 * 9 * 504 * 8
+    _audit_fields(r["roofline"], link_bytes=1 * 6 * 9 * 504 * 8)
 
 
 def test_eight_ranks_one_gpu_default_run_groups_3_3_2():

@@ -184,3 +184,30 @@ def test_errors_are_agreed_over_the_world(tmp_path):
         first, second = open(os.path.join(str(tmp_path), f"agree{r}.txt")).read().split("|")
         assert first == "None" and second == "rank 2: exchange buffer"
     assert sharded.agree_on_error("alone", 1) == "alone"                            # a single process: nothing to agree on
+
+
+def test_roofline_link_model_and_measured_traffic():
+    """sharded.ShardedRollout.roofline (pure arithmetic, no GPU): one directed xGMI link carries cnt_max*SX*9*B scalars per
+    step, the prediction is that over 153 GB/s, the batch above which a transport is link-bound follows from its assumed
+    fixed cost per exchange, and the measured HBM traffic comes from the transports' counter rows in profiles/traffic.json."""
+    from types import SimpleNamespace
+    cfg = config.panda_config(n_robots=3, horizon=30)
+    B, sb, sec = 65536, 8, 30 * 200e-6
+    for G, cnt_max, count, transport in ((3, 1, 1, "peer"), (2, 2, 2, "rccl"), (1, 3, 3, "peer")):
+        sr = SimpleNamespace(G=G, cnt_max=cnt_max, count=count, S=6, transport=transport)
+        r = sharded.ShardedRollout.roofline(cfg, sr, B, sb, sec)
+        link = r["link"]
+        cm = cnt_max if G > 1 else 1                        # world 1: the model is quoted for one robot per GPU
+        assert link["bytes_per_link_per_step"] == (cnt_max * 6 * 9 * B * sb if G > 1 else 0)
+        assert abs(link["predicted_ms_per_step"] - cm * 6 * 9 * sb * B / 153e9 * 1e3) < 1e-12
+        assert abs(link["measured_ms_per_step"] - 0.2) < 1e-12
+        assert link["model"]["link_bound_above_scenarios"]["peer"] == int(4.0e-6 * 153e9 / (cm * 432))
+        assert link["model"]["link_bound_above_scenarios"]["rccl"] == int(25.0e-6 * 153e9 / (cm * 432))
+        assert r["bound"] == ("xgmi_link" if G > 1 else "hbm")
+        # measured traffic: bytes per owned row and step of the transport's kernels x this rank's rows / step time
+        key = f"sharded_{transport}_f64"
+        assert r["traffic_key"] == key
+        import json
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")) as f:
+            e = json.load(f)[key]
+        assert abs(r["traffic"] - e["bytes_per_row_step"] * count * B / 200e-6 / 1e9) < 1e-6 * r["traffic"]
