@@ -403,12 +403,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           wp_pull<T, 6>(cfg, S, K, K.o[6], K.ao[6], acc.A[0], acc.b[0]);
           wp_pull<T, 6>(cfg, S, K, K.p8, K.a8, acc.A[1], acc.b[1]);
         }
-        // the goal parameters in one batch of loads after the pullbacks (a load issued where it is used costs an L2 round
-        // trip each; before the pullbacks there is no room for them)
+        // the goal parameters in ONE batch of loads after the pullbacks, pinned by a scheduling barrier: left to itself the
+        // scheduler sinks every load to its use (an L2 round trip each); before the pullbacks there is no room for them
         T gp[MRF_P_CONSTRAINT_0];
         if (forced) {
 #pragma unroll
           for (int i = 0; i < MRF_P_CONSTRAINT_0; ++i) gp[i] = P[i];
+          __builtin_amdgcn_sched_barrier(0);
           // attractor 0: panda_hand position -> x_goal_0   (EXJ:32-41)
           {
             T x0[3] = {K.p8[0] - gp[MRF_P_X_GOAL_0], K.p8[1] - gp[MRF_P_X_GOAL_0 + 1], K.p8[2] - gp[MRF_P_X_GOAL_0 + 2]};

@@ -57,7 +57,7 @@ def main():
                        "time (profiles/r05_wp_phases.txt).",
         },
         "k_rollout_panda_wp": {"counters": wp, "derived": derived(wp, 2), "vgpr": 256, "agpr": 0, "lds_bytes": 40384,
-                               "scratch_bytes_per_lane": 148, "waves_per_simd": 2},
+                               "scratch_bytes_per_lane": 140, "waves_per_simd": 2},
         "k_rollout_panda": {"counters": row, "derived": derived(row, 1), "vgpr": 256, "agpr": 250, "lds_bytes": 36992,
                             "scratch_bytes_per_lane": 0, "waves_per_simd": 1},
     }
