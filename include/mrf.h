@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MRF_ABI_VERSION 4
+#define MRF_ABI_VERSION 5
 #define MRF_MAX_ROBOTS 16
 #define MRF_MAX_SPHERES 32 /* exchanged spheres per robot */
 #define MRF_DOF_MAX 7

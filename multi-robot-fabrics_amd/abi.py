@@ -6,7 +6,7 @@ The product path has no CPU fallback: if csrc/libmrf_hip.so is missing or cannot
 import ctypes as C
 import os
 
-MRF_ABI_VERSION = 4
+MRF_ABI_VERSION = 5
 MRF_MAX_ROBOTS = 16
 MRF_MAX_SPHERES = 32
 MRF_DOF_MAX = 7
