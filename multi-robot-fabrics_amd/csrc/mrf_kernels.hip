@@ -1710,7 +1710,7 @@ int launch_coop(mrf_handle* h, int64_t n_scen, const void* q, const void* qd, co
 // The wave-pair form of the joint-space rollout (mrf_rollout_wp.hpp): float64, the reference's leaf strings and full
 // collision-link set, the link-origin sphere table with equal radii on the coincident origins.  Selected by
 // mrf_config.kernel_select = 3 (anything it does not cover runs the row-per-lane kernel), or for every handle by the
-// environment variable MRF_ROLLOUT_WP=1 (A/B on one box).  Not the default: measured 5-7 % slower than the row-per-lane
+// environment variable MRF_ROLLOUT_WP=1 (A/B on one box).  Not the default: measured 7-9 % slower than the row-per-lane
 // kernel on BASELINE config 4 (profiles/r05_wp_*.json).
 bool wave_pair_applies(const mrf_handle* h) {
   static const bool env_on = [] {
