@@ -100,17 +100,25 @@ CONSTANTS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "const
 LIBRARY_STRING_KEYS = ("limit_geometry", "limit_finsler", "finsler_plane_constraint")
 
 
+_constants_cache = {}      # (path, mtime) -> parsed file: configurations are built often, the file changes never or once
+
+
 def reconciled_constants():
     path = os.environ.get("MRF_CONSTANTS") or CONSTANTS_FILE
-    if not os.path.exists(path):
+    try:
+        key = (path, os.stat(path).st_mtime_ns)
+    except OSError:
         return {}
-    import json
-    with open(path) as f:
-        d = json.load(f)
-    unknown = [k for k in d if k not in ("fields", "strings", "_meta")]
-    if unknown:
-        raise ValueError(f"{path}: unknown sections {unknown}")
-    return d
+    if key not in _constants_cache:
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        unknown = [k for k in d if k not in ("fields", "strings", "_meta")]
+        if unknown:
+            raise ValueError(f"{path}: unknown sections {unknown}")
+        _constants_cache.clear()
+        _constants_cache[key] = d
+    return _constants_cache[key]
 
 
 def _apply_reconciled_fields(cfg):
