@@ -46,6 +46,7 @@ LEAF_K = ["limit_geometry", "limit_finsler", "plane_finsler"]
 FINSLER_CANDIDATES = {
     "gated 0.1/x": "0.1/(x ** 1) * (-0.5 * (ca.sign(xdot) - 1)) * xdot**2",
     "ungated 0.1/x^2": "0.1/(x ** 2) * xdot**2",
+    "gated 1.0/x": "1.0/(x ** 1) * (-0.5 * (ca.sign(xdot) - 1)) * xdot**2",      # a second recollection of the plane default
 }
 
 
