@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define MRF_ABI_VERSION 5
+#define MRF_ABI_VERSION 6
 #define MRF_MAX_ROBOTS 16
 #define MRF_MAX_SPHERES 32 /* exchanged spheres per robot */
 #define MRF_DOF_MAX 7
@@ -123,11 +123,27 @@ typedef struct {
   mrf_leaf_fn limit_geometry, limit_finsler;
   int32_t kernel_select; /* coupled kernels: 0 = auto by batch size, 1 = row-per-lane (throughput), 2 = one wave per scenario
                           * (latency), 3 = a pair of waves per row, two resident waves per SIMD (joint-space rollout with
-                          * float64, the reference's leaf strings and link-origin spheres; everything else as 1) */
+                          * float64, the reference's leaf strings and link-origin spheres; everything else -- and every
+                          * configuration in a library built without -DMRF_WITH_WP, mrf_build_has_wp() -- as 1) */
   int32_t ego_link_mask; /* panda7, n_ego == 6: bit (l-3) set = panda_link l (l = 3..8) carries collision and plane leaves --
                             the collision_links list of set_components (EXJ:91-96,123-125; the Cartesian rollout class
                             defaults to link 7 alone, FPC:20-21).  0x3F = all six (the examples' setting). */
+  int32_t exchange;      /* robot-sharded rollouts (mrf_rollout_sharded): what a robot puts on the wire per scenario and
+                          * step -- mrf_exchange_kind; 0 = MRF_EXCHANGE_JOINTS */
+  int32_t reserved_tail; /* 0 */
 } mrf_config;
+
+/* Payload of the exchange step of a robot-sharded rollout (FPJ:211-225 across GPUs), per robot, scenario and step:
+ *   MRF_EXCHANGE_JOINTS   cos q, sin q, qdot of the 7 joints = 21 scalars (168 B in float64) whatever the sphere table;
+ *                         the receiver re-walks the sender's chain (its mount is part of every rank's configuration) and
+ *                         streams the spheres x, v, a into its leaf sums -- the spheres themselves never exist in memory.
+ *   MRF_EXCHANGE_SPHERES  the SX = mrf_exchange_spheres() predicted spheres as 9 scalars each (x, v, a): 432 B for the
+ *                         reference's link-origin table, 1 440 B for 20 spheres -- the literal "all-gather of sphere
+ *                         centres".
+ * Either way robots that live on the SAME rank exchange on chip (per-wave LDS tile, as mrf_rollout does); only robots of
+ * other ranks go through the exchange buffers.  Results agree to round-off (different summation order). */
+typedef enum { MRF_EXCHANGE_JOINTS = 0, MRF_EXCHANGE_SPHERES = 1 } mrf_exchange_kind;
+#define MRF_JOINT_STATE_SCALARS 21 /* [7][3]: row 3*j + 0 = cos q_j, + 1 = sin q_j, + 2 = qdot_j */
 
 typedef struct mrf_handle mrf_handle;
 
@@ -148,6 +164,10 @@ int mrf_abi_version(void);
  * then refuses cfg.scalar = MRF_F32 with MRF_E_CONFIG.  The default build is float64 only -- the reference's arithmetic
  * (CasADi SX / DM); float32 is a throughput option for well-separated robots (accuracy: DESIGN.md section 3). */
 int mrf_build_has_f32(void);
+/* 1 when the library carries k_rollout_panda_wp (built with -DMRF_WITH_WP): kernel_select = 3 then runs the wave-pair
+ * rollout where it applies.  The default build does not (round 6: measured 7-9 % slower than the row-per-lane kernel,
+ * never auto-selected); kernel_select = 3 then runs the row-per-lane kernel. */
+int mrf_build_has_wp(void);
 int64_t mrf_config_sizeof(void); /* sizeof(mrf_config) as compiled, for FFI layout checks */
 
 /* Replaces ParameterizedFabricPlanner.compute_action (EXJ:441,444; EXC:447,449; FPC:150-190).
@@ -250,6 +270,19 @@ int mrf_step_predict(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, in
                      const void* qdot, void* sph_own, void* stream);
 int mrf_step_action(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
                     void* qdot_io, const void* params, const void* sph_all, void* sumsq_io, void* stream);
+/* The same step with the MRF_EXCHANGE_JOINTS payload:
+ *   mrf_step_predict_joints : q += dt*qdot for the owned robots; writes cos q, sin q, qdot  -> jst_own
+ *   <all-gather of the joint-state block across ranks>
+ *   mrf_step_action_joints  : fabric solve of the owned robots; the spheres of the robots of OTHER ranks are re-derived
+ *                             from jst_all by a chain walk per (lane, robot), the owned robots exchange theirs on chip
+ *                             (their entries of jst_all are read as the own state: cos q / sin q are not recomputed)
+ *   jst_own  [robot_count][21][n_scenarios]      jst_all  [n_robots][21][n_scenarios]   (MRF_JOINT_STATE_SCALARS rows) */
+int mrf_step_predict_joints(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, void* q_io,
+                            const void* qdot, void* jst_own, void* stream);
+int mrf_step_action_joints(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
+                           void* qdot_io, const void* params, const void* jst_all, void* sumsq_io, void* stream);
+/* scalars one robot puts on the wire per scenario and step under cfg.exchange: 21, or 9 * mrf_exchange_spheres() */
+int32_t mrf_exchange_scalars(const mrf_handle* h);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Robot-sharded rollout INSIDE the library (SURVEY 8b "mrf_comm_init / mrf_rollout_sharded", 8e).
@@ -298,10 +331,26 @@ int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot
  * i < n <= MRF_COMM_INFO_N:
  *   0 transport  1 rank  2 world  3 robot_first  4 robot_count
  *   5 ncclCommCount of the RCCL communicator (0: none)   6 ncclCommUserRank (-1: none)   7 ncclCommCuDevice (-1: none)
- *   8 HIP device of the handle   9 peer exchange buffers mapped from other ranks (PEER transport after connect) */
-#define MRF_COMM_INFO_N 10
+ *   8 HIP device of the handle   9 peer exchange buffers mapped from other ranks (PEER transport after connect)
+ *   10 cfg.exchange (mrf_exchange_kind)   11 scalars per robot, scenario and step on the wire (mrf_exchange_scalars)
+ *   12 peers whose mapped buffer lies on a device this one reaches in ONE hop (hipExtGetLinkTypeAndHopCount; -1: not
+ *      a connected PEER communicator) */
+#define MRF_COMM_INFO_N 13
 int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n);
 int32_t mrf_comm_transport(const mrf_handle* h);
+/* Where the exchange buffers of a connected PEER communicator really are, per rank g of the group: out[g*MRF_PEER_INFO_N + i]
+ *   0 device ordinal that owns the mapped allocation (hipPointerGetAttributes on the IPC mapping; the own rank: the
+ *     handle's device; -1: unknown)      1 hipDeviceCanAccessPeer(own device -> that device) (own rank: 1)
+ *   2 link type and 3 hop count of hipExtGetLinkTypeAndHopCount(own, that) (own rank / same device: 0, 0; -1: the call
+ *     failed)   link type: the HSA_AMD_LINK_INFO_TYPE_* value (2 = PCIe, 4 = xGMI)
+ * n = number of int32 available in out (>= world * MRF_PEER_INFO_N).  A first multi-GPU bench line can thereby show
+ * whether the peer stores crossed xGMI or fell back to PCIe. */
+#define MRF_PEER_INFO_N 4
+int mrf_comm_peer_info(const mrf_handle* h, int32_t* out, int32_t n);
+/* The node as HIP shows it to this process, no handle needed: *n_devices = hipGetDeviceCount; for i, j < min(n_devices,
+ * cap): can_access[i*cap + j] = hipDeviceCanAccessPeer(i, j) (diagonal 1), link_type / hops[i*cap + j] from
+ * hipExtGetLinkTypeAndHopCount (diagonal 0; -1 where the call fails).  Does not create contexts on other devices. */
+int mrf_device_topology(int32_t* n_devices, int32_t* can_access, int32_t* link_type, int32_t* hops, int32_t cap);
 int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io, const void* params, void* avg_vel_out,
                         void* stream);
 /* Waits for the stream of the last mrf_rollout_sharded and reports a timed-out exchange (MRF_E_LAUNCH) or MRF_OK. */

@@ -6,7 +6,7 @@ The product path has no CPU fallback: if csrc/libmrf_hip.so is missing or cannot
 import ctypes as C
 import os
 
-MRF_ABI_VERSION = 5
+MRF_ABI_VERSION = 6
 MRF_MAX_ROBOTS = 16
 MRF_MAX_SPHERES = 32
 MRF_DOF_MAX = 7
@@ -63,6 +63,7 @@ class Config(C.Structure):
         ("plane_geometry", LeafFn), ("plane_finsler", LeafFn),
         ("limit_geometry", LeafFn), ("limit_finsler", LeafFn),
         ("kernel_select", C.c_int32), ("ego_link_mask", C.c_int32),
+        ("exchange", C.c_int32), ("reserved_tail", C.c_int32),
     ]
 
     def copy(self):
@@ -76,7 +77,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmrf_hip.so")
 
 EXPORTS = [
     "mrf_default_config_panda", "mrf_default_config_planar3", "mrf_create", "mrf_destroy", "mrf_last_error",
-    "mrf_abi_version", "mrf_build_has_f32", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
+    "mrf_abi_version", "mrf_build_has_f32", "mrf_build_has_wp", "mrf_config_sizeof", "mrf_compute_action", "mrf_compute_action_coupled", "mrf_rollout", "mrf_rollout_cartesian",
     "mrf_fk_spheres", "mrf_rollout_sphere_traj", "mrf_exchange_spheres", "mrf_step_prepare", "mrf_step_predict", "mrf_step_action",
     "mrf_default_deadlock_config", "mrf_deadlock_config_sizeof", "mrf_deadlock_init", "mrf_control_prepare", "mrf_deadlock_step", "mrf_apply_action",
     "mrf_episode_run",
@@ -85,13 +86,20 @@ EXPORTS = [
     "mrf_episode_set_pick_place", "mrf_rollout_cartesian_coupled", "mrf_episode_set_rollout", "mrf_rollout_clock", "mrf_episode_set_recorder",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
     "mrf_comm_info", "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
+    "mrf_step_predict_joints", "mrf_step_action_joints", "mrf_exchange_scalars", "mrf_comm_peer_info", "mrf_device_topology",
 ]
 
 ROLLOUT_JOINTSPACE, ROLLOUT_CARTESIAN = 0, 1
 TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2
+EXCHANGE_JOINTS, EXCHANGE_SPHERES = 0, 1        # mrf_config.exchange: what a robot-sharded rollout puts on the wire
+EXCHANGE_NAMES = {EXCHANGE_JOINTS: "joints", EXCHANGE_SPHERES: "spheres"}
+JOINT_STATE_SCALARS = 21
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 COMM_INFO_KEYS = ("transport", "rank", "world", "robot_first", "robot_count", "rccl_comm_count", "rccl_user_rank",
-                  "rccl_device", "hip_device", "peer_buffers_mapped")
+                  "rccl_device", "hip_device", "peer_buffers_mapped", "exchange", "exchange_scalars_per_robot",
+                  "peers_one_hop")
+PEER_INFO_KEYS = ("device", "can_access_peer", "link_type", "hops")
+LINK_TYPE_NAMES = {0: "same device", 1: "hypertransport", 2: "pcie", 3: "qpi", 4: "xgmi", -1: "unknown"}
 
 # rows of the int32 deadlock state (include/mrf.h MRF_DL_*)
 DL_LEADER, DL_FOLLOWER, DL_DEAD0, DL_DEAD1, DL_TIME_IN_DEADLOCK, DL_TIME_DEADLOCK_OUT, DL_TIME_STEP, DL_NONFINITE, DL_NSTATE = range(9)
@@ -242,6 +250,19 @@ def load_library(path=None):
         lib.mrf_comm_info.restype = C.c_int
     lib.mrf_comm_transport.argtypes = [vp]
     lib.mrf_comm_transport.restype = i32
+    if not (any_abi and not hasattr(lib, "mrf_exchange_scalars")):
+        lib.mrf_build_has_wp.argtypes = []
+        lib.mrf_build_has_wp.restype = C.c_int
+        lib.mrf_step_predict_joints.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
+        lib.mrf_step_predict_joints.restype = C.c_int
+        lib.mrf_step_action_joints.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+        lib.mrf_step_action_joints.restype = C.c_int
+        lib.mrf_exchange_scalars.argtypes = [vp]
+        lib.mrf_exchange_scalars.restype = i32
+        lib.mrf_comm_peer_info.argtypes = [vp, C.POINTER(i32), i32]
+        lib.mrf_comm_peer_info.restype = C.c_int
+        lib.mrf_device_topology.argtypes = [C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32]
+        lib.mrf_device_topology.restype = C.c_int
     lib.mrf_rollout_sharded.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.mrf_rollout_sharded.restype = C.c_int
     lib.mrf_comm_status.argtypes = [vp]
@@ -261,6 +282,12 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def has_wp():
+    """True when the loaded library carries the wave-pair rollout kernel (built with -DMRF_WITH_WP; the default build does not)."""
+    lib = load_library()
+    return bool(lib.mrf_build_has_wp()) if hasattr(lib, "mrf_build_has_wp") else True
 
 
 def has_f32():

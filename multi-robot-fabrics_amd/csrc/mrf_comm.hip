@@ -2,19 +2,20 @@
 // library").  The exchange step of the reference's rollout graph (forward_planner_Jointspace.py:211-225:
 // at step k robot i reads the predicted spheres of every robot j != i) crosses GPUs here:
 //
-//   RCCL transport   host loop in C++: k_step_predict -> ncclAllGather -> k_step_action per horizon step, everything
-//                    enqueued on the caller's stream.  librccl is dlopen'ed (torch ships its own copy under the same
-//                    soname; whichever is already in the process is the one that gets used).
+//   RCCL transport   host loop in C++: predict -> ncclAllGather -> action per horizon step, everything enqueued on the
+//                    caller's stream (kernels: mrf_shard_step.hip).  librccl is dlopen'ed (torch ships its own copy under
+//                    the same soname; whichever is already in the process is the one that gets used).
 //   PEER transport   k_rollout_peer: ONE persistent kernel per rollout.  Workgroup = one wave = the owned robots of
-//                    floor(64/cnt_max) scenarios.  Per step a lane walks its chain once, stores its robot's sphere states
-//                    straight into every rank's exchange buffer (peer-mapped device memory: over xGMI between GPUs),
-//                    fences, raises the per-workgroup flag on every rank, polls the flags the peers raised for the
-//                    same scenarios, then folds the other robots' spheres from its LOCAL buffer and finishes the
-//                    solve.  Two buffer generations (step parity) are enough: a rank can publish step k+2 only after
-//                    it has seen every peer's step k+1 flag, which a peer raises after it finished reading step k.
-//                    Block X only ever waits for block X of the peers; the grid is capped at the resident workgroup
-//                    count and each workgroup walks its blocks in increasing order, so no wait can depend on a
-//                    workgroup that is not running.
+//                    floor(64/cnt_max) scenarios.  Per step a lane stores what its robot sends (mrf_config.exchange: its
+//                    joint state right after the position update, or its spheres after the chain walk) straight into
+//                    every OTHER rank's exchange buffer (peer-mapped device memory: over xGMI between GPUs), fences,
+//                    raises the per-workgroup flag on every rank, exchanges with the robots of its OWN rank on chip (LDS),
+//                    folds them, and only then polls the flags the peers raised for the same scenarios and folds the
+//                    remote robots from its LOCAL buffer.  Two buffer generations (step parity) are enough: a rank can
+//                    publish step k+2 only after it has seen every peer's step k+1 flag, which a peer raises after it
+//                    finished reading step k.  Block X only ever waits for block X of the peers; the grid is capped at
+//                    the resident workgroup count and each workgroup walks its blocks in increasing order, so no wait
+//                    can depend on a workgroup that is not running.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -26,6 +27,7 @@
 
 #include "mrf_device.hpp"
 #include "mrf_host.hpp"
+#include "mrf_shard.hpp"
 
 namespace mrf {
 
@@ -35,29 +37,34 @@ struct PeerView {
   int G, grank;                         // ranks in the group, own rank
   int first[MRF_MAX_ROBOTS + 1];        // robot block of rank g: [first[g], first[g+1])
   int nblk_max;                         // flag columns per rank
+  int xs;                               // scalars per robot and scenario in the buffers: 21 (joints) or 9 * SX (spheres)
   long long b_max;                      // scenario capacity of the buffers
   long long off_flags, off_err, off_x;  // byte offsets inside an allocation
   long long timeout_ticks;              // bounded spin, in wall_clock64 ticks
 };
 
-// flags: [2 generations][G source ranks][nblk_max]   spheres: [2][n_robots][SX][9][b_max]
+// flags: [2 generations][G source ranks][nblk_max]   payload: [2][n_robots][xs][b_max]
 __device__ __forceinline__ unsigned long long* peer_flag(const PeerView& V, int dst, int gen, int src, int blk) {
   return reinterpret_cast<unsigned long long*>(V.base[dst] + V.off_flags) + ((size_t)(gen * V.G + src) * V.nblk_max + blk);
 }
 template <typename T>
-__device__ __forceinline__ T* peer_x(const PeerView& V, int dst, int gen, int n_robots, int SX) {
-  return reinterpret_cast<T*>(V.base[dst] + V.off_x) + (size_t)gen * n_robots * SX * 9 * V.b_max;
+__device__ __forceinline__ T* peer_x(const PeerView& V, int dst, int gen, int n_robots) {
+  return reinterpret_cast<T*>(V.base[dst] + V.off_x) + (size_t)gen * n_robots * V.xs * V.b_max;
 }
 
-// Payload stores into an exchange buffer.  The buffer of another rank is an IPC mapping whose caching attributes on
-// the writer's side are the driver's choice, so those stores are made at system scope (write-through to the owner's
-// memory) instead of relying on the mapping being fine-grained; the own buffer takes plain stores.
+// Payload stores into another rank's exchange buffer.  That buffer is an IPC mapping whose caching attributes on the
+// writer's side are the driver's choice, so the stores are made at system scope (write-through to the owner's memory)
+// instead of relying on the mapping being fine-grained.
 template <typename T>
-__device__ __forceinline__ void xstore(T* p, T v, bool remote) {
-  if (remote)
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  else
-    *p = v;
+__device__ __forceinline__ void xstore(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and the reads of what the peers stored into the LOCAL buffer: system-scope loads, so that no cache level of this
+// device can answer with a line from the previous use of the generation (the buffer is fine-grained memory and the flags
+// were acquired at system scope; the scope on the load itself makes that independent of how the allocation is mapped)
+template <typename T>
+__device__ __forceinline__ T xload(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // a quiet NaN by bit pattern (this translation unit is compiled -ffast-math, where NaN literals are undefined)
@@ -68,16 +75,54 @@ __device__ __forceinline__ double quiet_nan<double>() { return __builtin_bit_cas
 template <>
 __device__ __forceinline__ float quiet_nan<float>() { return __builtin_bit_cast(float, 0x7fc00000u); }
 
+// The wave's payload stores are performed, then the per-workgroup flag goes up on every rank (own included: unused).
+// Once the group is in error (this rank timed out, or a peer did and said so in this rank's error word) no further flag
+// goes up: the payload behind it may have been computed from stale data, and the peers must time out -- or see the error
+// -- rather than fold it.
+__device__ __forceinline__ void peer_raise_flags(const PeerView& V, int gen, int blk, unsigned long long seq, const int* err,
+                                                 int etag, int lane) {
+  __threadfence_system();
+  __syncthreads();
+  const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
+  if (lane < V.G && lane != V.grank && !broken)
+    __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// wait for the same workgroup of every other rank (bounded: a missing peer must not hang the GPU)
+__device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int blk, unsigned long long seq, const int* err,
+                                                int etag, int lane) {
+  if (lane < V.G && lane != V.grank) {
+    const unsigned long long* f = peer_flag(V, V.grank, gen, lane, blk);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
+      if (wall_clock64() - t0 > V.timeout_ticks) {
+        // the timeout is the GROUP's: raise the error word of every rank, so that a peer which went on with this
+        // rank's (now missing) payload cannot return a finite result either
+        for (int g = 0; g < V.G; ++g)
+          __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every lane reads the peers' payload after the flags
+}
+
 // q_in / qd_in are only read; the advanced state and the velocity signal go to the STAGING arrays q_st / qd_st / avg_st
 // (owned by the communicator) and are committed to the caller's arrays by k_peer_commit after the whole grid has
 // finished -- from ONE reading of the error word, so that a timed-out exchange leaves every row where it was.
-template <typename T, class LS, bool LO>
+// XK: what the robots of OTHER ranks send (mrf_shard.hpp); XK_NONE = a group of one rank, which then runs the fused
+// kernel's step (all robots on chip, single chain walk) inside this kernel's persistent block loop.
+template <typename T, class LS, bool LO, int XK>
 __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict__ cfgp, PeerView V, int64_t n_scen,
                                                       const T* __restrict__ q_in, const T* __restrict__ qd_in,
                                                       const T* __restrict__ prm, T* __restrict__ q_st,
                                                       T* __restrict__ qd_st, T* __restrict__ avg_st,
                                                       unsigned long long seq0) {
-  __shared__ T xch[21 * 64];  // cos q, sin q, qdot of every lane (sphere tables with offsets re-walk from it)
+  __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
+  constexpr bool REMOTE = XK != XK_NONE;
   const DevCfg<T>& cfg = *cfgp;
   const int N = cfg.n_robots;
   const int first = V.first[V.grank], count = V.first[V.grank + 1] - first;
@@ -86,6 +131,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   const int spw = 64 / cnt_max;  // scenarios per block: the same on every rank, so block X is the same scenarios
   const int lane = threadIdx.x;
   const int nblk = (int)((n_scen + spw - 1) / spw);
+  if constexpr (LO) stage_sphere_radii(cfg, xch, lane);  // visible after the first barrier; never overwritten
   // The grid is capped at what is resident at once (host side); a workgroup then walks blocks blockIdx.x,
   // blockIdx.x + gridDim.x, ... in increasing order.  Block X only ever waits for block X of the peers, every workgroup
   // of every rank is resident and visits its blocks in increasing index order, so the wait graph has no cycle whatever
@@ -93,23 +139,25 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 #pragma unroll 1
   for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
   int ls = lane / count;
-  const int l = lane - ls * count;
+  const int l0 = lane - ls * count;
   int64_t scen = (int64_t)blk * spw + ls;
   const bool active = ls < spw && scen < n_scen;
   if (!active) {  // idle lanes shadow the block's first row (no stores)
     ls = 0;
     scen = (int64_t)blk * spw;
   }
-  const int me = first + (active ? l : 0);
+  const int l = active ? l0 : 0;
+  const int me = first + l;
   const int64_t rows = n_scen * count;
-  const int64_t row = scen * count + (active ? l : 0);
+  const int64_t row = scen * count + l;
   const int m01 = LO ? cfg.lo_merge01 : 0, m45 = LO ? cfg.lo_merge45 : 0;
-  const int SX = cfg.n_spheres - m01 - m45;
   int* err = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
   // The error word is tagged with the reset epoch (the high bits of every sequence number, mrf_comm_reset): "broken" means
   // "holds THIS epoch's tag", so a kernel of the previous epoch that times out late -- after a peer's reset has already
   // started the next epoch -- cannot break the new sequence with its store.
   const int etag = (int)(seq0 >> 40) + 1;
+  // without collision leaves (the grasp planner) nobody reads anybody's spheres: no payload, no flags, on every rank
+  const bool exchanging = REMOTE && V.G > 1 && cfg.n_ego > 0;
 
   PandaState<T> R;
   load_state(rows, row, q_in, qd_in, R);
@@ -122,7 +170,6 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
     for (int c = 0; c < 3; ++c) P.g0[c] = K0.p8[c] + cfg.goal_T * K0.v8[c];
     P.own_goal = true;
   }
-  const bool dyn = cfg.dynamic != 0;
   T sumsq = T(0);
   const int H = cfg.horizon;
 #pragma unroll 1
@@ -152,116 +199,89 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 #pragma unroll
       for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
     }
-    if constexpr (!LO) {
-      __syncthreads();
+    if constexpr (XK == XK_JOINTS) {
+      // ---- publish: the joint state of step k goes out BEFORE the own chain walk, so that the flag round trip runs
+      // under the walk and the local fold (FPJ:211-225 across GPUs; the receivers re-walk this chain)
+      if (exchanging) {
+        if (active) {
+          for (int g = 0; g < V.G; ++g) {
+            if (g == V.grank) continue;
+            T* dst = peer_x<T>(V, g, gen, N) + ((size_t)me * MRF_JOINT_STATE_SCALARS) * V.b_max + scen;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        xch[(3 * j + 0) * 64 + lane] = R.cq[j];
-        xch[(3 * j + 1) * 64 + lane] = R.sq[j];
-        xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+            for (int j = 0; j < 7; ++j) {
+              xstore(dst + (size_t)(3 * j + 0) * V.b_max, R.cq[j]);
+              xstore(dst + (size_t)(3 * j + 1) * V.b_max, R.sq[j]);
+              xstore(dst + (size_t)(3 * j + 2) * V.b_max, R.qd[j]);
+            }
+          }
+        }
+        peer_raise_flags(V, gen, blk, seq, err, etag, lane);
       }
-      __syncthreads();
     }
-    const T* xloc = peer_x<T>(V, V.grank, gen, N, SX);
+    const T* xloc = peer_x<T>(V, V.grank, gen, N);
     T qdd[7], act[7];
-    panda_solve_row<LS, LO && kSingleWalk<LS>>(
-        cfg, mount_own, R, P,
-        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          // fold the spheres of every other robot from the LOCAL exchange buffer (step k's generation), one flat
-          // software-pipelined loop over (other robot, slot) pairs
-          pipelined_pairs<T, 9>(
-              (N - 1) * SX,
-              [&](int m, T (&buf)[9]) {
-                const int d = m / SX, slot = m - d * SX;
-                int jr = me + 1 + d;
-                if (jr >= N) jr -= N;
-                const T* src = xloc + ((size_t)(jr * SX + slot) * 9) * V.b_max + scen;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) buf[c] = src[(size_t)c * V.b_max];
-              },
-              [&](int m, T (&buf)[9]) {
-                const int slot = m % SX;
-                const int s = LO ? lo_sphere(slot, m01, m45) : slot;
-                const T mult = LO ? T(lo_count(slot, m01, m45)) : T(1);
-                T v[3], a[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  v[c] = dyn ? buf[3 + c] : T(0);
-                  a[c] = dyn ? buf[6 + c] : T(0);
-                }
-                accumulate_obstacle<typename LS::Collision>(cfg, E, buf, v, a, cfg.sphere_r[s], false, acc, mult);
-              });
-        },
-        qdd, act,
+    sharded_solve_row<LS, LO, REMOTE>(
+        cfg, xch, lane, ls, l, count, mount_own, R, P,
         [&](const PandaKin<T>& K1) {
-          // ---- publish: this robot's spheres of step k into every rank's buffer (FPJ:211-225 across GPUs)
-          if (active) {
-            for (int g = 0; g < V.G; ++g) {
-              const bool remote = g != V.grank;
-              T* dst = peer_x<T>(V, g, gen, N, SX) + ((size_t)me * SX * 9) * V.b_max + scen;
-              if constexpr (LO) {
+          if constexpr (XK == XK_SPHERES) {
+            // ---- publish: this robot's spheres of step k into every other rank's buffer
+            if (!exchanging) return;
+            const int SX = cfg.n_spheres - m01 - m45;
+            if (active) {
+              for (int g = 0; g < V.G; ++g) {
+                if (g == V.grank) continue;
+                T* dst = peer_x<T>(V, g, gen, N) + ((size_t)me * SX * 9) * V.b_max + scen;
+                if constexpr (LO) {
 #pragma unroll
-                for (int sp = 0; sp < 8; ++sp) {
-                  if ((sp == 1 && m01) || (sp == 5 && m45)) continue;  // coincident link origins travel once
-                  T* d9 = dst + ((size_t)lo_slot(sp, m01, m45) * 9) * V.b_max;
+                  for (int sp = 0; sp < 8; ++sp) {
+                    if ((sp == 1 && m01) || (sp == 5 && m45)) continue;  // coincident link origins travel once
+                    T* d9 = dst + ((size_t)lo_slot(sp, m01, m45) * 9) * V.b_max;
 #pragma unroll
-                  for (int c = 0; c < 3; ++c) {
-                    xstore(d9 + (size_t)c * V.b_max, sp < 7 ? K1.o[sp < 7 ? sp : 0][c] : K1.p8[c], remote);
-                    xstore(d9 + (size_t)(3 + c) * V.b_max, sp < 7 ? K1.vo[sp < 7 ? sp : 0][c] : K1.v8[c], remote);
-                    xstore(d9 + (size_t)(6 + c) * V.b_max, cfg.jsign * (sp < 7 ? K1.ao[sp < 7 ? sp : 0][c] : K1.a8[c]), remote);
+                    for (int c = 0; c < 3; ++c) {
+                      xstore(d9 + (size_t)c * V.b_max, sp < 7 ? K1.o[sp < 7 ? sp : 0][c] : K1.p8[c]);
+                      xstore(d9 + (size_t)(3 + c) * V.b_max, sp < 7 ? K1.vo[sp < 7 ? sp : 0][c] : K1.v8[c]);
+                      xstore(d9 + (size_t)(6 + c) * V.b_max, cfg.jsign * (sp < 7 ? K1.ao[sp < 7 ? sp : 0][c] : K1.a8[c]));
+                    }
                   }
-                }
-              } else {
-                panda_walk_spheres<false, T>(
-                    cfg, mount_own,
-                    [&](int j, T& c, T& s, T& qdj) {
-                      c = xch[(3 * j + 0) * 64 + lane];
-                      s = xch[(3 * j + 1) * 64 + lane];
-                      qdj = xch[(3 * j + 2) * 64 + lane];
-                    },
-                    [&](int s, const T* x, const T* v, const T* a) {
-                      T* d9 = dst + ((size_t)s * 9) * V.b_max;
+                } else {
+                  panda_walk_spheres<false, T>(
+                      cfg, mount_own,
+                      [&](int j, T& c, T& s, T& qdj) {
+                        c = xch[(3 * j + 0) * 64 + lane];
+                        s = xch[(3 * j + 1) * 64 + lane];
+                        qdj = xch[(3 * j + 2) * 64 + lane];
+                      },
+                      [&](int s, const T* x, const T* v, const T* a) {
+                        T* d9 = dst + ((size_t)s * 9) * V.b_max;
 #pragma unroll
-                      for (int c = 0; c < 3; ++c) {
-                        xstore(d9 + (size_t)c * V.b_max, x[c], remote);
-                        xstore(d9 + (size_t)(3 + c) * V.b_max, v[c], remote);
-                        xstore(d9 + (size_t)(6 + c) * V.b_max, cfg.jsign * a[c], remote);
-                      }
-                    });
+                        for (int c = 0; c < 3; ++c) {
+                          xstore(d9 + (size_t)c * V.b_max, x[c]);
+                          xstore(d9 + (size_t)(3 + c) * V.b_max, v[c]);
+                          xstore(d9 + (size_t)(6 + c) * V.b_max, cfg.jsign * a[c]);
+                        }
+                      });
+                }
               }
             }
+            peer_raise_flags(V, gen, blk, seq, err, etag, lane);
           }
-          if (V.G == 1) {  // a group of one: the only reader of these stores is this very wave
-            __syncthreads();
-            return;
+        },
+        [&]() {
+          if (exchanging) peer_wait_flags(V, gen, blk, seq, err, etag, lane);
+        },
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+          if constexpr (XK == XK_JOINTS) {
+            remote_obstacles_joints<typename LS::Collision, LO>(
+                cfg, xch, lane, first, count, N,
+                [&](int jr, int c) { return xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * V.b_max + scen); }, E, acc);
+          } else if constexpr (XK == XK_SPHERES) {
+            const int SX = cfg.n_spheres - m01 - m45;
+            remote_obstacles_spheres<typename LS::Collision, LO>(
+                cfg, first, count, N,
+                [&](int jr, int slot, int c) { return xload(xloc + ((size_t)(jr * SX + slot) * 9 + c) * V.b_max + scen); }, E, acc);
           }
-          __threadfence_system();  // the wave's stores (local and remote) are performed before the flags go up
-          __syncthreads();
-          // Once the group is in error (this rank timed out, or a peer did and said so in this rank's error word) no
-          // further flag goes up: the spheres behind it may have been computed from stale data, and the peers must
-          // time out -- or see the error -- rather than fold them.
-          const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
-          if (lane < V.G && !broken)
-            __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          // ---- wait for the same workgroup of every other rank (bounded: a missing peer must not hang the GPU)
-          if (lane < V.G && lane != V.grank) {
-            const unsigned long long* f = peer_flag(V, V.grank, gen, lane, blk);
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-              if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
-              if (wall_clock64() - t0 > V.timeout_ticks) {
-                // the timeout is the GROUP's: raise the error word of every rank, so that a peer which went on with
-                // this rank's (now missing) spheres cannot return a finite result either
-                for (int g = 0; g < V.G; ++g)
-                  __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-              }
-              __builtin_amdgcn_s_sleep(1);
-            }
-          }
-          __syncthreads();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every lane reads the peers' spheres after the flags
-        });
+        },
+        qdd, act);
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       R.qd[j] = act[j];  // FPJ:233
@@ -281,7 +301,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 }
 
 // After k_rollout_peer (same stream): one thread latches the error word, then every row is committed from that latch --
-// all rows advance, or (a timed-out exchange: some step folded stale spheres) none does and the velocity signal is NaN,
+// all rows advance, or (a timed-out exchange: some step folded stale payload) none does and the velocity signal is NaN,
 // so that a caller that forgets mrf_comm_status cannot take the result for a rollout.
 __global__ void k_peer_latch(const int* __restrict__ err, int* __restrict__ latch, int group, int etag) {
   *latch = group > 1 ? (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) : 0;
@@ -390,11 +410,12 @@ struct Comm {
   int rank = 0, world = 1;
   int first[MRF_MAX_ROBOTS + 1] = {0};  // robot blocks
   int cnt_max = 1;
+  int xs = MRF_JOINT_STATE_SCALARS;  // scalars one robot sends per scenario and step (cfg.exchange at creation)
   // RCCL
   ncclComm_t nccl = nullptr;
   int nccl_count = 0, nccl_rank = -1, nccl_device = -1;  // what the communicator itself reports (mrf_comm_info)
-  void* sph_own = nullptr;  // [cnt_max][SX][9][B]
-  void* sph_pad = nullptr;  // [world][cnt_max][SX][9][B]
+  void* sph_own = nullptr;  // [cnt_max][xs][B]           xs = SX*9 sphere scalars or the 21 joint-state scalars
+  void* sph_pad = nullptr;  // [world][cnt_max][xs][B]
   void* sumsq = nullptr;    // [B*count]
   void* prm_work = nullptr; // [MRF_NPARAM][B*count]: params with the RF-CV goal estimate applied
   int64_t cap_scen = 0;
@@ -429,12 +450,15 @@ int check_group(mrf_handle* h, int rank, int world) {
     return fail(h, MRF_E_ARG, "world must be in 1..n_robots (further GPUs replicate the group over scenario batches)");
   if (rank < 0 || rank >= world) return fail(h, MRF_E_ARG, "rank out of range");
   if (h->comm) return fail(h, MRF_E_ARG, "the handle already has a communicator (mrf_comm_destroy first)");
+  if (h->cfg.exchange != MRF_EXCHANGE_JOINTS && h->cfg.exchange != MRF_EXCHANGE_SPHERES)
+    return fail(h, MRF_E_CONFIG, "cfg.exchange must be MRF_EXCHANGE_JOINTS or MRF_EXCHANGE_SPHERES");
   return MRF_OK;
 }
 
 size_t scalar_bytes(const mrf_handle* h) { return h->cfg.scalar == MRF_F64 ? 8 : 4; }
 
-int exchange_spheres(const mrf_handle* h) { return mrf_exchange_spheres(h); }
+int exchange_scalars(const mrf_handle* h) { return mrf_exchange_scalars(h); }
+bool joints_exchange(const mrf_handle* h) { return h->cfg.exchange == MRF_EXCHANGE_JOINTS; }
 
 int ensure_rccl_buffers(mrf_handle* h, Comm* c, int64_t n_scen) {
   if (n_scen <= c->cap_scen) return MRF_OK;
@@ -444,7 +468,7 @@ int ensure_rccl_buffers(mrf_handle* h, Comm* c, int64_t n_scen) {
   if (c->prm_work) (void)hipFree(c->prm_work);
   c->sph_own = c->sph_pad = c->sumsq = c->prm_work = nullptr;
   c->cap_scen = 0;
-  const size_t blk = (size_t)c->cnt_max * exchange_spheres(h) * 9 * n_scen * scalar_bytes(h);
+  const size_t blk = (size_t)c->cnt_max * c->xs * n_scen * scalar_bytes(h);
   hipError_t e = hipMalloc(&c->sph_pad, blk * c->world);
   if (e == hipSuccess) e = hipMemset(c->sph_pad, 0, blk * c->world);
   if (e == hipSuccess && c->world > 1) e = hipMalloc(&c->sph_own, blk);
@@ -513,6 +537,7 @@ int mrf_comm_init(mrf_handle* h, int32_t rank, int32_t world, const void* unique
   Comm* c = new Comm();
   c->rank = rank;
   c->world = world;
+  c->xs = exchange_scalars(h);
   partition(*c, h->cfg.n_robots);
   if (unique_id) {
     RcclApi& api = rccl();
@@ -540,10 +565,19 @@ int mrf_comm_init(mrf_handle* h, int32_t rank, int32_t world, const void* unique
 int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n) {
   if (!h || !out || n < 1) return MRF_E_ARG;
   const Comm* c = (const Comm*)h->comm;
+  int32_t one_hop = -1;
+  if (c && c->transport == MRF_TRANSPORT_PEER && c->connected) {
+    one_hop = 0;
+    int32_t pi[MRF_MAX_ROBOTS * MRF_PEER_INFO_N];
+    if (mrf_comm_peer_info(h, pi, MRF_MAX_ROBOTS * MRF_PEER_INFO_N) == MRF_OK)
+      for (int g = 0; g < c->world; ++g)
+        if (g != c->rank && pi[g * MRF_PEER_INFO_N + 3] == 1) one_hop += 1;
+  }
   const int32_t vals[MRF_COMM_INFO_N] = {
       c ? c->transport : MRF_TRANSPORT_NONE, c ? c->rank : 0, c ? c->world : 0, c ? c->first[c->rank] : 0,
       c ? c->first[c->rank + 1] - c->first[c->rank] : 0, c ? c->nccl_count : 0, c ? c->nccl_rank : -1,
-      c ? c->nccl_device : -1, h->device, c && c->transport == MRF_TRANSPORT_PEER && c->connected ? c->world - 1 : 0};
+      c ? c->nccl_device : -1, h->device, c && c->transport == MRF_TRANSPORT_PEER && c->connected ? c->world - 1 : 0,
+      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop};
   for (int i = 0; i < n && i < MRF_COMM_INFO_N; ++i) out[i] = vals[i];
   return MRF_OK;
 }
@@ -557,6 +591,7 @@ int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_s
   c->rank = rank;
   c->world = world;
   c->transport = MRF_TRANSPORT_PEER;
+  c->xs = exchange_scalars(h);
   partition(*c, h->cfg.n_robots);
   const int spw = 64 / c->cnt_max;
   c->b_max = max_scenarios;
@@ -564,7 +599,7 @@ int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_s
   c->off_flags = 0;
   c->off_err = ((size_t)2 * world * c->nblk_max * sizeof(unsigned long long) + 255) & ~(size_t)255;
   c->off_x = c->off_err + 256;
-  c->bytes = c->off_x + (size_t)2 * h->cfg.n_robots * exchange_spheres(h) * 9 * c->b_max * scalar_bytes(h);
+  c->bytes = c->off_x + (size_t)2 * h->cfg.n_robots * c->xs * c->b_max * scalar_bytes(h);
   // fine-grained device memory: coherent for the peers' stores and this GPU's loads while kernels are running
   hipError_t e = hipExtMallocWithFlags((void**)&c->local, c->bytes, hipDeviceMallocFinegrained);
   if (e == hipSuccess) e = hipMemset(c->local, 0, c->bytes);
@@ -610,6 +645,67 @@ int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all) {
   return MRF_OK;
 }
 
+int mrf_comm_peer_info(const mrf_handle* h, int32_t* out, int32_t n) {
+  if (!h || !out) return MRF_E_ARG;
+  const Comm* c = (const Comm*)h->comm;
+  if (!c || c->transport != MRF_TRANSPORT_PEER || !c->connected) return MRF_E_ARG;
+  if (n < c->world * MRF_PEER_INFO_N) return MRF_E_ARG;
+  for (int g = 0; g < c->world; ++g) {
+    int32_t* o = out + g * MRF_PEER_INFO_N;
+    if (g == c->rank) {
+      o[0] = h->device; o[1] = 1; o[2] = 0; o[3] = 0;
+      continue;
+    }
+    o[0] = o[2] = o[3] = -1;
+    o[1] = 0;
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof(at));
+    if (c->peer[g] && hipPointerGetAttributes(&at, c->peer[g]) == hipSuccess) o[0] = at.device;
+    (void)hipGetLastError();
+    if (o[0] < 0) continue;
+    if (o[0] == h->device) {  // several ranks on one device (the single-GPU tests)
+      o[1] = 1; o[2] = 0; o[3] = 0;
+      continue;
+    }
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, h->device, o[0]) == hipSuccess) o[1] = can;
+    uint32_t lt = 0, hops = 0;
+    if (hipExtGetLinkTypeAndHopCount(h->device, o[0], &lt, &hops) == hipSuccess) {
+      o[2] = (int32_t)lt;
+      o[3] = (int32_t)hops;
+    }
+    (void)hipGetLastError();
+  }
+  return MRF_OK;
+}
+
+int mrf_device_topology(int32_t* n_devices, int32_t* can_access, int32_t* link_type, int32_t* hops, int32_t cap) {
+  if (!n_devices || cap < 0) return MRF_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    *n_devices = 0;
+    return MRF_E_DEVICE;
+  }
+  *n_devices = n;
+  const int m = n < cap ? n : cap;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      int can = i == j;
+      uint32_t lt = 0, hp = 0;
+      bool ok = true;
+      if (i != j) {
+        if (hipDeviceCanAccessPeer(&can, i, j) != hipSuccess) can = 0;
+        ok = hipExtGetLinkTypeAndHopCount(i, j, &lt, &hp) == hipSuccess;
+        (void)hipGetLastError();
+      }
+      if (can_access) can_access[i * cap + j] = can;
+      if (link_type) link_type[i * cap + j] = ok ? (int32_t)lt : -1;
+      if (hops) hops[i * cap + j] = ok ? (int32_t)hp : -1;
+    }
+  return MRF_OK;
+}
+
 int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot_count) {
   if (!h || !h->comm) return MRF_E_ARG;
   const Comm* c = (const Comm*)h->comm;
@@ -643,6 +739,7 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     V.grank = c->rank;
     for (int g = 0; g <= c->world; ++g) V.first[g] = c->first[g];
     V.nblk_max = c->nblk_max;
+    V.xs = c->xs;
     V.b_max = c->b_max;
     V.off_flags = (long long)c->off_flags;
     V.off_err = (long long)c->off_err;
@@ -688,16 +785,19 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         return launch(h, mrf::k_peer_commit<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, rows, (const int*)latch,
                       (const T*)q_st, (const T*)qd_st, (const T*)avg_st, (T*)q_io, (T*)qdot_io, (T*)avg_vel_out);
       };
-      if (lo) return go(mrf::k_rollout_peer<T, LS, true>);
-      return go(mrf::k_rollout_peer<T, LS, false>);
+      // what the robots of other ranks send: nothing (a group of one: the fused kernel's step), joint states, spheres
+      if (c->world == 1) return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_NONE>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_NONE>);
+      if (c->xs == MRF_JOINT_STATE_SCALARS)
+        return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_JOINTS>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_JOINTS>);
+      return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_SPHERES>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_SPHERES>);
     });
   }
 
   // ---- RCCL (or a group of one): predict -> all-gather -> action per horizon step, all on `st`
   if (int rc = ensure_rccl_buffers(h, c, n_scen)) return rc;
   if (int rc = check_hip(h, hipMemsetAsync(c->sumsq, 0, (size_t)rows * scalar_bytes(h), st), "hipMemsetAsync")) return rc;
-  const int SX = exchange_spheres(h);
-  const size_t per_rank = (size_t)c->cnt_max * SX * 9 * n_scen;
+  const bool joints = c->xs == MRF_JOINT_STATE_SCALARS;
+  const size_t per_rank = (size_t)c->cnt_max * c->xs * n_scen;
   int32_t slots[MRF_MAX_ROBOTS];
   for (int j = 0; j < MRF_MAX_ROBOTS; ++j) slots[j] = 0;
   for (int g = 0; g < c->world; ++g)
@@ -709,13 +809,17 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     params = c->prm_work;
   }
   for (int k = 0; k < H; ++k) {
-    if (int rc = mrf_step_predict(h, n_scen, first, count, q_io, qdot_io, own, st)) return rc;
+    if (int rc = joints ? mrf_step_predict_joints(h, n_scen, first, count, q_io, qdot_io, own, st)
+                        : mrf_step_predict(h, n_scen, first, count, q_io, qdot_io, own, st))
+      return rc;
     if (c->nccl) {
       ncclResult_t r = rccl().AllGather(own, c->sph_pad, per_rank, h->cfg.scalar == MRF_F64 ? ncclDouble : ncclFloat,
                                         c->nccl, st);
       if (r != ncclSuccess) return fail(h, MRF_E_LAUNCH, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
     }
-    if (int rc = mrf_host::step_action_slots(h, n_scen, first, count, q_io, qdot_io, params, c->sph_pad, slots, c->sumsq, st))
+    if (int rc = joints ? mrf_host::step_action_joints_slots(h, n_scen, first, count, q_io, qdot_io, params, c->sph_pad, slots,
+                                                             c->sumsq, st)
+                        : mrf_host::step_action_slots(h, n_scen, first, count, q_io, qdot_io, params, c->sph_pad, slots, c->sumsq, st))
       return rc;
   }
   dim3 block(256), grid((unsigned)((rows + 255) / 256));

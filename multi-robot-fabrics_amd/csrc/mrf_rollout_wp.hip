@@ -1,6 +1,9 @@
 // mrf_rollout_wp.hip -- translation unit of k_rollout_panda_wp (mrf_rollout_wp.hpp): the coupled joint-space rollout
 // (FPJ:190-249) as a pair of waves per row.  Its own unit because it builds the device header in the SGPR-literal flavour
 // (two waves per SIMD, no spare VGPRs for hoisted float64 literals), the other kernels in the VGPR-literal one.
+// Opt-in since round 6 (-DMRF_WITH_WP, MRF_WITH_WP=1 for __graft_entry__.build()): the kernel measures 7-9 % slower than the
+// row-per-lane kernel and is never auto-selected, so the default library does not carry it (mrf_build_has_wp()).
+#ifdef MRF_WITH_WP
 #define MRF_SGPR_CONST 1
 #include <hip/hip_runtime.h>
 
@@ -21,3 +24,4 @@ int mrf_host::rollout_wave_pair(mrf_handle* h, int64_t n_scen, const void* q0, c
                 (const mrf::DevCfg<double>*)h->dcfg, n_scen, (const double*)q0, (const double*)qdot0, (const double*)params,
                 (double*)avg_out, (double*)traj_q, (double*)traj_qd, (long long*)h->clock_probe, h->rollout_serial);
 }
+#endif  // MRF_WITH_WP

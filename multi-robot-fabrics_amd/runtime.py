@@ -20,6 +20,19 @@ def _dtype(cfg):
     return torch.float64 if cfg.scalar == abi.F64 else torch.float32
 
 
+def device_topology(cap=16):
+    """The node as HIP shows it to this process (mrf_device_topology; no handle, no context on other devices):
+    {"n_devices", "can_access_peer" [n][n], "link_type" [n][n] (names), "hops" [n][n]}."""
+    lib = abi.load_library()
+    n = C.c_int32(0)
+    can, lt, hp = ((C.c_int32 * (cap * cap))() for _ in range(3))
+    rc = lib.mrf_device_topology(C.byref(n), can, lt, hp, cap)
+    m = max(0, min(int(n.value), cap))
+    grid = lambda a, f=int: [[f(a[i * cap + j]) for j in range(m)] for i in range(m)]
+    return {"n_devices": int(n.value), "status": abi.STATUS_TEXT.get(rc, str(rc)), "can_access_peer": grid(can),
+            "link_type": grid(lt, lambda v: abi.LINK_TYPE_NAMES.get(int(v), str(int(v)))), "hops": grid(hp)}
+
+
 class FabricHandle:
     """Owns an `mrf_handle` (immutable constants on the device).  Not thread-safe, like the C handle."""
 
@@ -255,6 +268,31 @@ class FabricHandle:
                                       self._arg(sumsq_io, (rows,), "sumsq_io"), self._stream(stream))
         self._check(rc)
 
+    @property
+    def exchange_scalars(self):
+        """Scalars one robot puts on the wire per scenario and step under cfg.exchange: 21 (joints) or 9 * exchange_spheres."""
+        return int(self.lib.mrf_exchange_scalars(self._h))
+
+    def step_predict_joints(self, n_scen, robot_first, robot_count, q_io, qdot, jst_own, stream=None):
+        """q_io += dt*qdot for the owned robots; cos q, sin q, qdot -> jst_own [count, 21, n_scen] (MRF_EXCHANGE_JOINTS)."""
+        rows = n_scen * robot_count
+        rc = self.lib.mrf_step_predict_joints(self._h, n_scen, robot_first, robot_count,
+                                              self._arg(q_io, (self.dof, rows), "q_io"),
+                                              self._arg(qdot, (self.dof, rows), "qdot"),
+                                              self._arg(jst_own, (robot_count, abi.JOINT_STATE_SCALARS, n_scen), "jst_own"),
+                                              self._stream(stream))
+        self._check(rc)
+
+    def step_action_joints(self, n_scen, robot_first, robot_count, q, qdot_io, params, jst_all, sumsq_io, stream=None):
+        """Fabric solve of the owned robots: the owned robots exchange on chip, the others are re-walked from jst_all
+        [n_robots, 21, n_scen]; qdot_io := action, sumsq_io += |action|^2."""
+        rows = n_scen * robot_count
+        rc = self.lib.mrf_step_action_joints(self._h, n_scen, robot_first, robot_count, self._arg(q, (self.dof, rows), "q"),
+                                             self._arg(qdot_io, (self.dof, rows), "qdot_io"),
+                                             self._arg(params, (abi.NPARAM, rows), "params"),
+                                             self._arg(jst_all, (self.cfg.n_robots, abi.JOINT_STATE_SCALARS, n_scen), "jst_all"),
+                                             self._arg(sumsq_io, (rows,), "sumsq_io"), self._stream(stream))
+        self._check(rc)
 
     # ------------------------------------------------------------------ host-buffer entry points (numpy in, numpy out)
     @staticmethod
@@ -371,6 +409,23 @@ class FabricHandle:
             raise MrfError("mrf_comm_info failed")
         out = dict(zip(abi.COMM_INFO_KEYS, (int(v) for v in vals)))
         out["transport"] = {abi.TRANSPORT_NONE: "none", abi.TRANSPORT_RCCL: "rccl", abi.TRANSPORT_PEER: "peer"}[out["transport"]]
+        out["exchange"] = abi.EXCHANGE_NAMES.get(out["exchange"], str(out["exchange"]))
+        return out
+
+    def comm_peer_info(self):
+        """Connected PEER communicator: per rank of the group, where its exchange buffer really is as seen from this rank --
+        owning device of the mapping, hipDeviceCanAccessPeer, link type and hop count (mrf_comm_peer_info)."""
+        world = self.comm_info()["world"]
+        vals = (C.c_int32 * (world * len(abi.PEER_INFO_KEYS)))()
+        if self.lib.mrf_comm_peer_info(self._h, vals, len(vals)) != 0:
+            raise MrfError("mrf_comm_peer_info: no connected PEER communicator")
+        n = len(abi.PEER_INFO_KEYS)
+        out = []
+        for g in range(world):
+            d = dict(zip(abi.PEER_INFO_KEYS, (int(v) for v in vals[g * n:(g + 1) * n])))
+            d["rank"] = g
+            d["link"] = abi.LINK_TYPE_NAMES.get(d["link_type"], str(d["link_type"]))
+            out.append(d)
         return out
 
     def comm_partition(self):

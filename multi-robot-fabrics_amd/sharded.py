@@ -1,5 +1,8 @@
-"""Robot-sharded Rollout Fabrics: one robot (or a contiguous group of robots) per GPU, with an all-gather of the
-predicted collision-sphere states after every rollout step (the exchange step is FPJ:211-225).
+"""Robot-sharded Rollout Fabrics: one robot (or a contiguous group of robots) per GPU, with an exchange between the
+ranks after every rollout step (the exchange step is FPJ:211-225).  What a robot sends is cfg.exchange
+(include/mrf.h mrf_exchange_kind): its JOINT STATE (cos q, sin q, qdot: 21 scalars -- the receivers re-walk its chain;
+the default since round 6) or its predicted collision SPHERES (SX x 9 scalars, the literal all-gather of sphere
+centres).  Robots that live on the same rank exchange on chip either way.
 
     world = sum of group sizes   the ranks are filled with groups of N ranks (one robot per GPU, the north-star layout),
                      then ONE smaller group takes the remaining ranks: 3 robots on 1/2/4/8 GPUs -> [1], [2], [3, 1],
@@ -8,9 +11,10 @@ predicted collision-sphere states after every rollout step (the excha
                      different scenario batches, sized in inverse proportion to the group's robots per rank so that
                      all ranks finish together.
     per rollout step on every rank:
-        mrf_step_predict   q += dt*qdot for the owned robots; their spheres (x, v, a) -> sph_own [cnt, S, 9, B]
-        all_gather         over the ranks of the group (RCCL over xGMI on GPUs; gloo in the CPU tests)
-        mrf_step_action    fabric solve of the owned robots against everybody else's spheres; qdot := action
+        mrf_step_predict[_joints]  q += dt*qdot for the owned robots; their payload -> own [cnt, XS, B]
+        all_gather                 over the ranks of the group (RCCL over xGMI on GPUs; gloo in the CPU tests)
+        mrf_step_action[_joints]   fabric solve of the owned robots against everybody else's spheres; qdot := action
+    XS = 21 (joints) or SX*9 (spheres), SX = mrf_exchange_spheres.
 
 Three transports for the exchange:
     "torch"  the per-step loop in Python with torch.distributed.all_gather_into_tensor (gloo in the CPU tests of the
@@ -20,9 +24,10 @@ Three transports for the exchange:
     "peer"   mrf_rollout_sharded over peer-mapped exchange buffers: one persistent kernel per rollout, device-side stores
              into the peers' memory and flag polling; torch.distributed only carries the 64-byte IPC handles.
 
-The collective moves SX*9*B scalars per owned robot per step, SX = mrf_exchange_spheres (6 for the reference's 8
-link-origin spheres: the origins of links 1/2 and 5/6 coincide and travel once; B=1: 432 B in f64), so at small B it is latency-bound;
-batching scenarios is what makes the link time matter.  The compute backend is injectable so that the
+The collective moves XS*B scalars per owned robot per step: 21*B with the joint payload (B=1: 168 B in f64, whatever
+the sphere table), SX*9*B with the sphere payload (SX = 6 for the reference's 8 link-origin spheres, whose coincident
+origins of links 1/2 and 5/6 travel once: 432 B; 20 spheres: 1 440 B).  At small B it is latency-bound; batching
+scenarios is what makes the link time matter.  The compute backend is injectable so that the
 partitioning / gather logic is testable on CPU ranks (tests pass an oracle-backed stand-in); the default backend
 is the HIP kernels and there is no CPU fallback.
 """
@@ -107,6 +112,12 @@ class HipStepBackend:
     def action(self, n_scen, first, count, q, qd_io, prm, sph_all, sumsq):
         self.h.step_action(n_scen, first, count, q, qd_io, prm, sph_all, sumsq)
 
+    def predict_joints(self, n_scen, first, count, q_io, qd, jst_own):
+        self.h.step_predict_joints(n_scen, first, count, q_io, qd, jst_own)
+
+    def action_joints(self, n_scen, first, count, q, qd_io, prm, jst_all, sumsq):
+        self.h.step_action_joints(n_scen, first, count, q, qd_io, prm, jst_all, sumsq)
+
 
 class ShardedRollout:
     def __init__(self, cfg, rank, world, backend=None, device_index=0, transport="torch", max_scenarios=None):
@@ -122,7 +133,12 @@ class ShardedRollout:
         self.uniform = all(c == self.cnt_max for _, c in self.parts)
         self.backend = backend if backend is not None else HipStepBackend(cfg, device_index)
         self.dtype, self.device = self.backend.dtype, self.backend.device
-        self.S = getattr(self.backend, "exchange_spheres", cfg.n_spheres)   # spheres per robot on the wire
+        self.S = getattr(self.backend, "exchange_spheres", cfg.n_spheres)   # spheres per robot on the wire (sphere payload)
+        if cfg.exchange not in abi.EXCHANGE_NAMES:
+            raise ValueError("cfg.exchange must be abi.EXCHANGE_JOINTS or abi.EXCHANGE_SPHERES")
+        self.exchange = abi.EXCHANGE_NAMES[cfg.exchange]
+        self.joints = cfg.exchange == abi.EXCHANGE_JOINTS
+        self.XS = abi.JOINT_STATE_SCALARS if self.joints else 9 * self.S     # scalars per robot, scenario and step on the wire
         self.group = None
         if world > 1:
             # one communicator per replica; every rank must take part in every new_group call
@@ -200,21 +216,24 @@ class ShardedRollout:
         if self.transport != "torch":
             return self.backend.h.rollout_sharded(q, qd, prm)
         n_scen = q.shape[1] // self.count
-        S, H = self.S, self.H
-        sph_pad = torch.zeros((self.G, self.cnt_max, S, 9, n_scen), dtype=self.dtype, device=self.device)
-        sph_own = sph_pad[self.grank] if self.G == 1 else torch.zeros((self.cnt_max, S, 9, n_scen), dtype=self.dtype,
-                                                                        device=self.device)
+        H = self.H
+        shape = (abi.JOINT_STATE_SCALARS,) if self.joints else (self.S, 9)      # one robot's payload per scenario
+        predict = self.backend.predict_joints if self.joints else self.backend.predict
+        action = self.backend.action_joints if self.joints else self.backend.action
+        pad = torch.zeros((self.G, self.cnt_max) + shape + (n_scen,), dtype=self.dtype, device=self.device)
+        own = pad[self.grank] if self.G == 1 else torch.zeros((self.cnt_max,) + shape + (n_scen,), dtype=self.dtype,
+                                                               device=self.device)
         sumsq = torch.zeros((n_scen * self.count,), dtype=self.dtype, device=self.device)
         if (self.cfg.goal_estimate_mask >> self.first) & ((1 << self.count) - 1):
             prm = self.backend.prepare(n_scen, self.first, self.count, q, qd, prm)     # RF-CV goal estimate (EXC:355-357)
         for _ in range(H):
-            self.backend.predict(n_scen, self.first, self.count, q, qd, sph_own[:self.count])
+            predict(n_scen, self.first, self.count, q, qd, own[:self.count])
             if self.G > 1:
-                dist.all_gather_into_tensor(sph_pad.view(-1), sph_own.view(-1), group=self.group)
-            sph_all = sph_pad.view(self.G * self.cnt_max, S, 9, n_scen)
+                dist.all_gather_into_tensor(pad.view(-1), own.view(-1), group=self.group)
+            everybody = pad.view((self.G * self.cnt_max,) + shape + (n_scen,))
             if not self.uniform:
-                sph_all = sph_all.index_select(0, self._unpad)
-            self.backend.action(n_scen, self.first, self.count, q, qd, prm, sph_all, sumsq)
+                everybody = everybody.index_select(0, self._unpad)
+            action(n_scen, self.first, self.count, q, qd, prm, everybody, sumsq)
         return sumsq / (H * 7)
 
     # ------------------------------------------------------------------ bench leg (bench.py --shard robots)
@@ -269,7 +288,8 @@ class ShardedRollout:
             raise RuntimeError(f"robot-sharded rollout ({transport}): {err}")
         # what every rank saw: its communicator (as RCCL itself reports it), its device, its own time per rollout
         mine = {"rank": rank, "group": gi, "rollout_ms": own_ms, "device": device_identity(local_rank),
-                "comm": h.comm_info() if transport != "torch" else None}
+                "comm": h.comm_info() if transport != "torch" else None,
+                "peers": h.comm_peer_info() if transport == "peer" else None}
         ranks = [mine]
         if world > 1:
             ranks = [None] * world
@@ -298,10 +318,13 @@ class ShardedRollout:
             "config": {"workload": f"{N}-Panda RF-CV H={H} coupled rollout only", "scenarios_per_replica": B,
                        "robot_groups": sr.groups, "scenarios_per_group": per_group, "robots_per_rank_all": per_rank,
                        "robot_group_ranks": sr.G, "replicas": sr.D, "robots_per_rank": [c for _, c in sr.parts],
-                       "sharding": "robots (all-gather of SX*9*B sphere scalars per robot per rollout step)",
-                       "exchanged_spheres_per_robot": S},
+                       "sharding": f"robots ({sr.exchange} payload: {sr.XS} scalars per remote robot, scenario and rollout "
+                                   "step; robots of one rank exchange on chip)",
+                       "exchange": sr.exchange, "exchange_scalars_per_robot": sr.XS,
+                       "exchanged_spheres_per_robot": S if not sr.joints else None},
             "rollout_steps_per_s": rate * N * H,
-            "allgather_bytes_per_rank_per_step": sr.cnt_max * S * 9 * B * sb,
+            "allgather_bytes_per_rank_per_step": sr.cnt_max * sr.XS * B * sb,
+            "exchange": sr.exchange,
             "transport": transport,
             "rccl_ranks_seen": sorted({r["comm"]["rccl_comm_count"] for r in ranks if r["comm"]}) if transport == "rccl" else None,
             "rollout_ms_per_rank": {"min": min(r["rollout_ms"] for r in ranks), "max": max(r["rollout_ms"] for r in ranks),
@@ -322,11 +345,12 @@ class ShardedRollout:
     @staticmethod
     def roofline(cfg, sr, B, sb, seconds_per_rollout):
         """Two views of one robot-sharded rollout (H exchange steps).  Link view: on the xGMI mesh every rank sends its
-        sphere block to each of the G-1 peers over a separate link, so one directed link carries cnt_max*SX*9*B scalars
-        per step (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU).  HBM view: SURVEY 8d's algorithmic bytes per
-        rollout-step -- here the exchanged formulation is what actually runs (spheres do go through memory)."""
+        payload block to each of the G-1 peers over a separate link, so one directed link carries cnt_max*XS*B scalars
+        per step (XS = 21 joint-state scalars or SX*9 sphere scalars; MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU).
+        HBM view: SURVEY 8d's algorithmic bytes per rollout-step of the exchanged formulation (spheres through memory)."""
         N, H, S = cfg.n_robots, cfg.horizon, sr.S
-        link_bytes = sr.cnt_max * S * 9 * B * sb if sr.G > 1 else 0
+        XS = getattr(sr, "XS", 9 * S)
+        link_bytes = sr.cnt_max * XS * B * sb if sr.G > 1 else 0
         per_step = seconds_per_rollout / H
         alg = sb * (28 + 9 * S + 9 * S * (N - 1)) + sb * 23 / H            # per (robot, horizon step)
         hbm = alg * sr.count * B / per_step                                # this rank's rows
@@ -339,21 +363,24 @@ class ShardedRollout:
         out.update(achieved=top["achieved"], peak=top["peak"], unit="GB/s", frac=top["frac"], traffic=None)
         # measured HBM traffic of the transport's kernels (separate --pmc passes, profiles/traffic.json keys
         # sharded_<transport>_<dtype>: bytes per owned row and rollout step), scaled to this rank's rows
-        tr = ShardedRollout._traffic_entry(f"sharded_{sr.transport}_{'f64' if sb == 8 else 'f32'}")
+        xname = getattr(sr, "exchange", "spheres")
+        tr = ShardedRollout._traffic_entry(f"sharded_{sr.transport}_{xname}_{'f64' if sb == 8 else 'f32'}")
         if tr is not None:
             out["traffic"] = tr["bytes_per_row_step"] * sr.count * B / per_step / 1e9
             out["traffic_unit"], out["traffic_key"], out["traffic_kernels"] = "GB/s", tr["key"], tr.get("kernels")
         # Link model, stated so that the first run on real links audits itself: one directed xGMI link
         # carries cnt_max*SX*9*B scalars per step at <= 153 GB/s; the exchanged step is link-bound once that exceeds the
         # fixed cost of an exchange (flag round trip of the peer kernel / launch + collective latency of the RCCL path).
-        one = S * 9 * sb                                     # bytes per scenario, link and step with ONE robot per rank
+        one = XS * sb                                        # bytes per scenario, link and step with ONE robot per rank
         cm = sr.cnt_max if sr.G > 1 else 1
         fixed_us = {"peer": 4.0, "rccl": 25.0}               # assumed fixed cost per exchange [us]: measured 1.7 us flag
         out["link"].update(                                  # round trip on one die (tools/ipc_probe.hip); RCCL: typical
             predicted_ms_per_step=cm * one * B / 153e9 * 1e3,
             predicted_ms_per_rollout=cm * one * B / 153e9 * 1e3 * H,
             measured_ms_per_step=per_step * 1e3,
-            model={"bytes_per_scenario_link_step": cm * one, "link_GBps": 153.0, "assumed_fixed_us_per_exchange": fixed_us,
+            model={"bytes_per_scenario_link_step": cm * one, "payload": xname, "scalars_per_robot": XS,
+                   "spheres_payload_bytes_per_scenario_link_step": cm * 9 * S * sb,
+                   "link_GBps": 153.0, "assumed_fixed_us_per_exchange": fixed_us,
                    "link_bound_above_scenarios": {k: int(v * 1e-6 * 153e9 / (cm * one)) for k, v in fixed_us.items()},
                    "peer_vs_rccl": "per step the peer kernel costs max(kernel, link) + flag round trip, the RCCL path "
                                    "predict + all-gather + action in stream order = kernels + latency + link: in this "

@@ -28,10 +28,12 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
 
 
+@pytest.mark.parametrize("exchange", ["joints", "spheres"])
 @pytest.mark.parametrize("transport", ["rccl", "peer"])
 @pytest.mark.parametrize("n_robots,horizon,n_scen,table", [(3, 6, 37, "lo"), (2, 5, 130, "lo"), (3, 4, 21, "offsets")])
-def test_world1_matches_fused_rollout(transport, n_robots, horizon, n_scen, table):
+def test_world1_matches_fused_rollout(transport, n_robots, horizon, n_scen, table, exchange):
     cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+    cfg.exchange = {"joints": abi.EXCHANGE_JOINTS, "spheres": abi.EXCHANGE_SPHERES}[exchange]
     cfg.goal_estimate_mask = 0b110 & ((1 << n_robots) - 1)
     if table == "offsets":
         links, offs = config.sphere_offsets_per_link(2)
@@ -43,10 +45,14 @@ def test_world1_matches_fused_rollout(transport, n_robots, horizon, n_scen, tabl
     # the communicator as it reports itself (mrf_comm_info): for RCCL what ncclCommCount / UserRank / CuDevice return
     info = h.comm_info()
     assert (info["transport"], info["rank"], info["world"], info["robot_first"], info["robot_count"]) == (transport, 0, 1, 0, n_robots)
+    assert info["exchange"] == exchange
+    assert info["exchange_scalars_per_robot"] == (21 if exchange == "joints" else 9 * h.exchange_spheres) == h.exchange_scalars
     if transport == "rccl":
         assert (info["rccl_comm_count"], info["rccl_user_rank"]) == (1, 0) and info["rccl_device"] == info["hip_device"] == 0
     else:
         assert (info["rccl_comm_count"], info["rccl_user_rank"], info["peer_buffers_mapped"]) == (0, -1, 0)
+        assert info["peers_one_hop"] == 0 and h.comm_peer_info() == [
+            {"device": 0, "can_access_peer": 1, "link_type": 0, "hops": 0, "rank": 0, "link": "same device"}]
     q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
     want_avg, tq, tqd = FabricHandle(cfg, 0).rollout(q, qd, prm, want_traj=True)
     for _ in range(2):
@@ -78,21 +84,46 @@ def test_comm_argument_errors():
     assert h.comm_partition() == (0, 2)
 
 
-@pytest.mark.parametrize("n_robots,horizon,n_scen,table,dtype", [(2, 8, 50, "lo", "f64"), (3, 6, 45, "lo", "f64"),
-                                                                  (3, 4, 30, "offsets", "f64"), (2, 6, 40, "lo", "f32")])
-def test_two_processes_one_gpu_peer_exchange(n_robots, horizon, n_scen, table, dtype):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000", MRF_PEER_DEVICE_SHARE="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "sharded_worker.py"), str(n_robots),
-           str(horizon), str(n_scen), table, dtype]
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="8000", MRF_PEER_DEVICE_SHARE=str(world))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), str(n_robots),
+           str(horizon), str(n_scen), table, dtype, exchange]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    ranks = json.loads(line)["ranks"]
+    return json.loads(line)["ranks"]
+
+
+@pytest.mark.parametrize("exchange", ["joints", "spheres"])
+@pytest.mark.parametrize("n_robots,horizon,n_scen,table,dtype", [(2, 8, 50, "lo", "f64"), (3, 6, 45, "lo", "f64"),
+                                                                  (3, 4, 30, "offsets", "f64"), (2, 6, 40, "lo", "f32")])
+def test_two_processes_one_gpu_peer_exchange(n_robots, horizon, n_scen, table, dtype, exchange):
+    ranks = _run_group_on_one_gpu(2, n_robots, horizon, n_scen, table, dtype, exchange, 29547)
     assert sorted(r["count"] for r in ranks) == sorted([n_robots // 2, n_robots - n_robots // 2])
     tol = 1e-9 if dtype == "f64" else 2e-3
     for r in ranks:
         assert r["err"] < tol, ranks
+        assert r["exchange"] == exchange and r["scalars"] == (21 if exchange == "joints" else 9 * (6 if table == "lo" else 16))
+        # both ranks sit on device 0: the peer's mapped buffer is reported on the own device, zero hops
+        assert [p["device"] for p in r["peers"]] == [0, 0] and r["peers_one_hop"] == 0
+
+
+@pytest.mark.parametrize("world,n_robots,horizon,n_scen,table,exchange", [
+    (3, 3, 6, 40, "lo", "joints"),            # BASELINE config 4's placement: one robot per rank, two remote robots per lane
+    (3, 3, 5, 40, "lo", "spheres"),
+    (4, 4, 4, 33, "offsets", "joints"),       # four ranks, generic table: three remote chains re-walked one at a time
+    (4, 8, 3, 12, "offsets20", "joints"),     # BASELINE config 5's table on 4 ranks: 2 robots per rank on chip + 6 remote
+    (4, 8, 3, 12, "offsets20", "spheres"),
+])
+def test_three_and_four_processes_one_gpu_peer_exchange(world, n_robots, horizon, n_scen, table, exchange):
+    """More than one remote robot per lane (the remote chunk loop of mrf_shard.hpp), local AND remote robots in one wave,
+    BASELINE config 5's 20-sphere table: 21 scalars on the wire against 180."""
+    ranks = _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, "f64", exchange, 29551)
+    assert sorted(r["count"] for r in ranks) == [n_robots // world] * world
+    for r in ranks:
+        assert r["err"] < 1e-9, ranks
+        assert r["scalars"] == (21 if exchange == "joints" else 9 * {"lo": 6, "offsets": 16, "offsets20": 20}[table])
 
 
 def test_plain_c_consumer_two_processes_one_gpu():

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from multi_robot_fabrics_amd import config, scenarios, sharded
+from multi_robot_fabrics_amd import abi, config, scenarios, sharded
 
 
 class OracleStepBackend:
@@ -81,15 +81,38 @@ class OracleStepBackend:
         sumsq += torch.from_numpy((act ** 2).sum(0))
 
 
-def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir):
+    # ---- the joint-state payload (MRF_EXCHANGE_JOINTS): cos q, sin q, qdot travel, the receiver derives the spheres
+    def predict_joints(self, n_scen, first, count, q_io, qd, jst_own):
+        q_io += self.cfg.dt * qd
+        qn, qdn = q_io.numpy().reshape(7, n_scen, count), qd.numpy().reshape(7, n_scen, count)
+        out = np.zeros((count, 21, n_scen))
+        out[:, 0::3, :] = np.cos(qn).transpose(2, 0, 1)
+        out[:, 1::3, :] = np.sin(qn).transpose(2, 0, 1)
+        out[:, 2::3, :] = qdn.transpose(2, 0, 1)
+        jst_own[:] = torch.from_numpy(out)
+
+    def action_joints(self, n_scen, first, count, q, qd_io, prm, jst_all, sumsq):
+        S, N = self.cfg.n_spheres, self.cfg.n_robots
+        ja = jst_all.numpy()                                                  # [N,21,B]
+        q_all = np.arctan2(ja[:, 1::3, :], ja[:, 0::3, :])                    # [N,7,B]
+        qf = q_all.transpose(1, 2, 0).reshape(7, n_scen * N)                  # column = scenario*N + robot
+        qdf = ja[:, 2::3, :].transpose(1, 2, 0).reshape(7, n_scen * N)
+        x, v, a = self.o.fk_spheres(self.cfg, qf, qdf)                        # [S,3,B*N]
+        full = np.concatenate([x, v, a], axis=1).reshape(S, 9, n_scen, N)
+        self.action(n_scen, first, count, q, qd_io, prm, torch.from_numpy(full.transpose(3, 0, 1, 2).copy()), sumsq)
+
+
+def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir, exchange="joints"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
         cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1      # RF-CV
+        cfg.exchange = {"joints": abi.EXCHANGE_JOINTS, "spheres": abi.EXCHANGE_SPHERES}[exchange]
         batch = scenarios.panda_batch(cfg, n_scen, seed=77, x_min=0.08)
         sr = sharded.ShardedRollout(cfg, rank, world, backend=OracleStepBackend(cfg))
+        assert sr.XS == (21 if exchange == "joints" else 9 * cfg.n_spheres)
         rows = sr.own_rows(n_scen).numpy()
         q = torch.from_numpy(np.ascontiguousarray(batch["q"][:, rows]))
         qd = torch.from_numpy(np.ascontiguousarray(batch["qdot"][:, rows]))
@@ -107,10 +130,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("exchange", ["joints", "spheres"])
 @pytest.mark.parametrize("n_robots", [2, 3])        # 3 robots on 2 ranks: uneven blocks (2 + 1), padded gather
-def test_sharded_rollout_world2_matches_fused(oracle, tmp_path, n_robots):
+def test_sharded_rollout_world2_matches_fused(oracle, tmp_path, n_robots, exchange):
     world, H, B = 2, 4, 5
-    mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path), exchange), nprocs=world, join=True)
     cfg = config.panda_config(n_robots=n_robots, horizon=H)
     cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1
     batch = scenarios.panda_batch(cfg, B, seed=77, x_min=0.08)
@@ -126,13 +150,14 @@ def test_sharded_rollout_world2_matches_fused(oracle, tmp_path, n_robots):
     assert sorted(seen) == list(range(B * n_robots))       # every (scenario, robot) row owned exactly once
 
 
-def test_sharded_rollout_world4_three_robots_one_per_rank_plus_a_group_of_one(oracle, tmp_path):
+@pytest.mark.parametrize("exchange", ["joints", "spheres"])
+def test_sharded_rollout_world4_three_robots_one_per_rank_plus_a_group_of_one(oracle, tmp_path, exchange):
     """BASELINE config 4 on the 1/2/4/8 ladder: 3 robots on 4 ranks form the groups [3] + [1] (sharded.group_layout) --
     ranks 0..2 own one robot each and exchange spheres every step, rank 3 is a replica that carries all three robots and
     exchanges nothing.  Both groups must reproduce the fused rollout."""
     world, n_robots, H, B = 4, 3, 3, 4
     assert sharded.group_layout(n_robots, world) == [3, 1]
-    mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_robots, H, B, str(tmp_path), exchange), nprocs=world, join=True)
     cfg = config.panda_config(n_robots=n_robots, horizon=H)
     cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1
     batch = scenarios.panda_batch(cfg, B, seed=77, x_min=0.08)
@@ -150,8 +175,10 @@ def test_sharded_rollout_world4_three_robots_one_per_rank_plus_a_group_of_one(or
     assert sorted(seen[0]) == sorted(seen[1]) == list(range(B * n_robots))
 
 
-def test_single_rank_needs_no_process_group(oracle):
+@pytest.mark.parametrize("exchange", [abi.EXCHANGE_JOINTS, abi.EXCHANGE_SPHERES])
+def test_single_rank_needs_no_process_group(oracle, exchange):
     cfg = config.panda_config(n_robots=2, horizon=3)
+    cfg.exchange = exchange
     batch = scenarios.panda_batch(cfg, 3, seed=5, x_min=0.08)
     sr = sharded.ShardedRollout(cfg, 0, 1, backend=OracleStepBackend(cfg))
     q, qd, prm = (torch.from_numpy(batch[k].copy()) for k in ("q", "qdot", "params"))
@@ -187,27 +214,40 @@ def test_errors_are_agreed_over_the_world(tmp_path):
 
 
 def test_roofline_link_model_and_measured_traffic():
-    """sharded.ShardedRollout.roofline (pure arithmetic, no GPU): one directed xGMI link carries cnt_max*SX*9*B scalars per
-    step, the prediction is that over 153 GB/s, the batch above which a transport is link-bound follows from its assumed
-    fixed cost per exchange, and the measured HBM traffic comes from the transports' counter rows in profiles/traffic.json."""
+    """sharded.ShardedRollout.roofline (pure arithmetic, no GPU): one directed xGMI link carries cnt_max*XS*B scalars per
+    step (XS = 21 joint-state scalars, or SX*9 sphere scalars), the prediction is that over 153 GB/s, the batch above which
+    a transport is link-bound follows from its assumed fixed cost per exchange, and the measured HBM traffic comes from the
+    transports' counter rows in profiles/traffic.json.  VERDICT r5 item 1: the joint payload cuts the predicted link time
+    >= 2.5x on BASELINE config 4 (432 -> 168 B) and >= 8x on config 5 (1 440 -> 168 B)."""
+    import json
     from types import SimpleNamespace
     cfg = config.panda_config(n_robots=3, horizon=30)
     B, sb, sec = 65536, 8, 30 * 200e-6
-    for G, cnt_max, count, transport in ((3, 1, 1, "peer"), (2, 2, 2, "rccl"), (1, 3, 3, "peer")):
-        sr = SimpleNamespace(G=G, cnt_max=cnt_max, count=count, S=6, transport=transport)
-        r = sharded.ShardedRollout.roofline(cfg, sr, B, sb, sec)
-        link = r["link"]
-        cm = cnt_max if G > 1 else 1                        # world 1: the model is quoted for one robot per GPU
-        assert link["bytes_per_link_per_step"] == (cnt_max * 6 * 9 * B * sb if G > 1 else 0)
-        assert abs(link["predicted_ms_per_step"] - cm * 6 * 9 * sb * B / 153e9 * 1e3) < 1e-12
-        assert abs(link["measured_ms_per_step"] - 0.2) < 1e-12
-        assert link["model"]["link_bound_above_scenarios"]["peer"] == int(4.0e-6 * 153e9 / (cm * 432))
-        assert link["model"]["link_bound_above_scenarios"]["rccl"] == int(25.0e-6 * 153e9 / (cm * 432))
-        assert r["bound"] == ("xgmi_link" if G > 1 else "hbm")
-        # measured traffic: bytes per owned row and step of the transport's kernels x this rank's rows / step time
-        key = f"sharded_{transport}_f64"
-        assert r["traffic_key"] == key
-        import json
-        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")) as f:
-            e = json.load(f)[key]
-        assert abs(r["traffic"] - e["bytes_per_row_step"] * count * B / 200e-6 / 1e9) < 1e-6 * r["traffic"]
+    pred = {}
+    for exchange, XS in (("joints", 21), ("spheres", 54)):
+        for G, cnt_max, count, transport in ((3, 1, 1, "peer"), (2, 2, 2, "rccl"), (1, 3, 3, "peer")):
+            sr = SimpleNamespace(G=G, cnt_max=cnt_max, count=count, S=6, XS=XS, exchange=exchange, transport=transport)
+            r = sharded.ShardedRollout.roofline(cfg, sr, B, sb, sec)
+            link = r["link"]
+            cm = cnt_max if G > 1 else 1                        # world 1: the model is quoted for one robot per GPU
+            assert link["bytes_per_link_per_step"] == (cnt_max * XS * B * sb if G > 1 else 0)
+            assert abs(link["predicted_ms_per_step"] - cm * XS * sb * B / 153e9 * 1e3) < 1e-12
+            assert abs(link["measured_ms_per_step"] - 0.2) < 1e-12
+            assert link["model"]["link_bound_above_scenarios"]["peer"] == int(4.0e-6 * 153e9 / (cm * XS * sb))
+            assert link["model"]["link_bound_above_scenarios"]["rccl"] == int(25.0e-6 * 153e9 / (cm * XS * sb))
+            assert link["model"]["payload"] == exchange and link["model"]["scalars_per_robot"] == XS
+            assert r["bound"] == ("xgmi_link" if G > 1 else "hbm")
+            pred[(exchange, G)] = link["predicted_ms_per_step"]
+            # measured traffic: bytes per owned row and step of the transport's kernels x this rank's rows / step time
+            key = f"sharded_{transport}_{exchange}_f64"
+            with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")) as f:
+                e = json.load(f).get(key)
+            if e is not None:
+                assert r["traffic_key"] == key
+                assert abs(r["traffic"] - e["bytes_per_row_step"] * count * B / 200e-6 / 1e9) < 1e-6 * r["traffic"]
+    assert pred[("spheres", 3)] / pred[("joints", 3)] >= 2.5                    # BASELINE config 4, one robot per GPU
+    c5 = SimpleNamespace(G=8, cnt_max=1, count=1, S=20, transport="peer")
+    cfg5 = config.panda_config(n_robots=8, horizon=50)
+    p5 = {x: sharded.ShardedRollout.roofline(cfg5, SimpleNamespace(**vars(c5), XS=xs, exchange=x), B, sb, sec)["link"]["predicted_ms_per_step"]
+          for x, xs in (("joints", 21), ("spheres", 180))}
+    assert p5["spheres"] / p5["joints"] >= 8.0                                   # BASELINE config 5: 1 440 B -> 168 B
