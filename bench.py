@@ -282,6 +282,8 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     res = {"workload": spec["label"], "kernel": kernel, "scenarios": B, "robots": N, "horizon": H, "spheres_per_robot": S,
+           "batch_rule": f"{CONFIG_ROUNDS} rounds of the chip's resident single-wave workgroups (4 per CU x {64 // N} scenarios); "
+                         "rounds 1-4 quoted 2 rounds, SURVEY 8d's C2 points are B in {1, 4096, 65536}",
            "kernel_ms": ms, "launches_timed": iters, "unit": unit_name, "units_per_s": units / (ms * 1e-3),
            "scenarios_per_s": B / (ms * 1e-3), "dtype": dtype}
     peak_tf = (F64_VECTOR_PEAK if dtype == "f64" else 2 * F64_VECTOR_PEAK) / 1e12
@@ -292,7 +294,7 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
     if src is not None and "flops_per_unit" in src:
         tf = units * src["flops_per_unit"] / (ms * 1e-3) / 1e12
         roof.update(bound="valu_" + dtype, achieved=tf, peak=peak_tf, unit="TFLOP/s", frac=tf / peak_tf,
-                    flops_per_unit=src["flops_per_unit"], traffic_key=key,
+                    flops_per_unit=src["flops_per_unit"], traffic_key=key, traffic_key_exact=bool(key.endswith(f"_B{B}")),
                     traffic=(src["bytes_per_launch"] / (ms * 1e-3) / 1e9) if key.endswith(f"_B{B}") else None, traffic_unit="GB/s")
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from make_traffic import kernel_source_sha256
@@ -327,34 +329,56 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
     return res
 
 
+def node_topology():
+    """What HIP shows this process of the node (mrf_device_topology): device count, hipDeviceCanAccessPeer matrix, link type and
+    hop count of every device pair (hipExtGetLinkTypeAndHopCount) -- recorded before the sharded block so that a first
+    multi-GPU line shows whether the peer stores had xGMI links to cross.  Never fatal."""
+    try:
+        from multi_robot_fabrics_amd.runtime import device_topology
+        t = device_topology()
+        t["visible_devices_env"] = {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+                                    if k in os.environ}
+        return t
+    except Exception as e:      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+SHARDED_KEYS = ("value", "unit", "ms_per_step", "rollout_steps_per_s", "steps", "exchange", "allgather_bytes_per_rank_per_step",
+                "parity_vs_fused_kernel", "roofline", "rccl_ranks_seen", "rollout_ms_per_rank", "devices", "distinct_devices",
+                "ranks")
+
+
 def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
     """Secondary block of the default run: the north-star partitioning (robots of a scenario spread over the GPUs of a
-    group, per-step exchange of predicted sphere states) on the same batch, rollout only, for both
-    transports of include/mrf.h.  At world 1 the group is one GPU (no link traffic): it prices the exchanged
-    formulation's kernels against the fused one.  Never fatal: a transport that cannot be set up is reported as text."""
+    group, per-step exchange between the ranks) on the same batch, rollout only, for both transports of
+    include/mrf.h and both payloads (mrf_config.exchange): keys `rccl` / `peer` = the joint-state payload (21 scalars per
+    remote robot; the default), `rccl_spheres` / `peer_spheres` = the sphere payload (the literal all-gather of sphere
+    centres).  `topology` = the node as HIP shows it.  At world 1 the group is one GPU (no link traffic): it prices the
+    sharded machinery against the fused kernel.  Never fatal: a transport that cannot be set up is reported as text."""
     import copy
+    from multi_robot_fabrics_amd import abi, sharded
     from multi_robot_fabrics_amd.sharded import ShardedRollout
-    out = {}
+    out = {"topology": node_topology() if rank == 0 else None}
     a = copy.copy(args)
     a.steps, a.warmup = max(1, min(args.steps, 10)), 1
-    from multi_robot_fabrics_amd import sharded
     # the first (largest) group works on the headline's per-GPU batch; a group with more robots per rank gets
     # proportionally fewer scenarios (sharded.group_scenarios), so that all ranks finish together
     a.scenarios = args.scenarios * sharded.robots_per_rank_max(cfg_roll.n_robots, sharded.group_layout(cfg_roll.n_robots, world)[0])
     if world > 1:       # the ranks of a robot group work on the same scenarios: one batch per group, made once
         batch = None
     # two ranks sharing one GPU (the test hook) cannot form an RCCL communicator: only the peer transport runs there
-    for transport in (("peer",) if os.environ.get("MRF_BENCH_SHARE_GPU") == "1" else ("rccl", "peer")):
-        a.transport = transport
-        try:
-            r = ShardedRollout.bench(cfg_roll, batch, a, rank, world, local_rank)
-            out[transport] = {k: r[k] for k in ("value", "unit", "ms_per_step", "rollout_steps_per_s", "steps",
-                                                "allgather_bytes_per_rank_per_step", "parity_vs_fused_kernel", "roofline",
-                                                "rccl_ranks_seen", "rollout_ms_per_rank", "devices", "distinct_devices",
-                                                "ranks")}
-            out[transport]["config"] = r["config"]
-        except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
-            out[transport] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    for exchange, xk, suffix in (("joints", abi.EXCHANGE_JOINTS, ""), ("spheres", abi.EXCHANGE_SPHERES, "_spheres")):
+        cfg = cfg_roll.copy()
+        cfg.exchange = xk
+        for transport in (("peer",) if os.environ.get("MRF_BENCH_SHARE_GPU") == "1" else ("rccl", "peer")):
+            a.transport = transport
+            key = transport + suffix
+            try:
+                r = ShardedRollout.bench(cfg, batch, a, rank, world, local_rank)
+                out[key] = {k: r[k] for k in SHARDED_KEYS}
+                out[key]["config"] = r["config"]
+            except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
     return out
 
 
@@ -473,6 +497,9 @@ def main():
     ap.add_argument("--shard", choices=["scenarios", "robots"], default="scenarios")
     ap.add_argument("--transport", choices=["rccl", "peer", "torch"], default="rccl",
                     help="--shard robots: exchange inside the library over RCCL (default) or peer-mapped buffers, or the Python loop")
+    ap.add_argument("--exchange", choices=["joints", "spheres"], default="joints",
+                    help="--shard robots: what a remote robot sends per scenario and step -- its joint state (21 scalars, the "
+                         "receivers re-walk its chain) or its predicted spheres (SX x 9 scalars)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-robot-shard", action="store_true", help="skip the secondary robot-sharded block of the default run")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (C2, C3, C5, Cartesian rollout) of the --gpus 1 line")
@@ -542,8 +569,10 @@ def main():
     if args.shard == "robots":
         from multi_robot_fabrics_amd.sharded import ShardedRollout
         args.scenarios = B
+        cfg_roll.exchange = {"joints": abi.EXCHANGE_JOINTS, "spheres": abi.EXCHANGE_SPHERES}[args.exchange]
         result = ShardedRollout.bench(cfg_roll, batch if world == 1 else None, args, rank, world, local_rank)
         if rank == 0:
+            result["topology"] = node_topology()
             emit(result)
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -652,6 +681,8 @@ def main():
                                    f"compute_action against the M={(N - 1) * S} spheres of the other robots",
                        "scenarios_per_gpu": B, "robots": N, "horizon": H, "spheres_per_robot": S,
                        "sharding": "scenarios (independent, no collective)"},
+            "constants": {"source": config.reconciled_constants_source() or "recalled defaults (SURVEY Appendix A; no constants.json)"},
+            "build": {"has_f32": bool(abi.has_f32()), "has_wp": bool(abi.has_wp()), "abi_version": abi.MRF_ABI_VERSION},
             "rollout_steps_per_s": world * units * args.steps / elapsed,
             "rollout_kernel_ms": roll_ms,
             "effective_clock_ghz": ghz,

@@ -285,12 +285,24 @@ def load_library(path=None):
 
 
 def has_wp():
-    """True when the loaded library carries the wave-pair rollout kernel (built with -DMRF_WITH_WP; the default build does not)."""
+    """True when the loaded library carries the wave-pair rollout kernel (built with -DMRF_WITH_WP; the default build does
+    not).  A library without the query symbol predates the switch (round 5 and earlier: the kernel was always built)."""
     lib = load_library()
     return bool(lib.mrf_build_has_wp()) if hasattr(lib, "mrf_build_has_wp") else True
 
 
 def has_f32():
-    """True when the loaded library carries the float32 kernels (built with -DMRF_WITH_F32; the default build does not)."""
+    """True when the loaded library carries the float32 kernels (built with -DMRF_WITH_F32; the default build does not).
+    A library without the query symbol (an older A/B build under MRF_ABI_ANY) is probed: mrf_create of a float32 handle
+    fails with MRF_E_CONFIG at validation -- before any device is touched -- exactly when the kernels are absent."""
     lib = load_library()
-    return bool(lib.mrf_build_has_f32()) if hasattr(lib, "mrf_build_has_f32") else True
+    if hasattr(lib, "mrf_build_has_f32"):
+        return bool(lib.mrf_build_has_f32())
+    cfg = Config()
+    lib.mrf_default_config_panda(C.byref(cfg), 2, 2)
+    cfg.scalar = F32
+    h = C.c_void_p()
+    rc = lib.mrf_create(C.byref(cfg), -1, C.byref(h))
+    if h:
+        lib.mrf_destroy(h)
+    return rc != -2

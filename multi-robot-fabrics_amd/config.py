@@ -103,11 +103,20 @@ LIBRARY_STRING_KEYS = ("limit_geometry", "limit_finsler", "finsler_plane_constra
 _constants_cache = {}      # (path, mtime) -> parsed file: configurations are built often, the file changes never or once
 
 
+# Only the RECALLED values may be reconciled: a constants file cannot rewrite the ABI version, the scalar type,
+# the model, robot counts or any other structural field of mrf_config.
+RECONCILABLE_FIELDS = ("eps", "jdot_sign", "goal_estimate_T", "base_mass", "attr_k", "attr_alpha", "attr_mu", "attr_ml", "attr_a",
+                       "beta_a", "beta_r", "beta_b", "beta_s", "eta_a", "eta_s", "plane_abs", "zero_small_action")
+
+
 def reconciled_constants():
-    path = os.environ.get("MRF_CONSTANTS") or CONSTANTS_FILE
+    explicit = os.environ.get("MRF_CONSTANTS")
+    path = explicit or CONSTANTS_FILE
     try:
         key = (path, os.stat(path).st_mtime_ns)
-    except OSError:
+    except OSError as e:
+        if explicit:        # a typo must not silently run the recalled defaults
+            raise FileNotFoundError(f"MRF_CONSTANTS={explicit!r} cannot be read: {e}") from e
         return {}
     if key not in _constants_cache:
         import json
@@ -123,9 +132,19 @@ def reconciled_constants():
 
 def _apply_reconciled_fields(cfg):
     for k, v in reconciled_constants().get("fields", {}).items():
-        if not hasattr(cfg, k):
-            raise KeyError(f"reconciled constants: unknown mrf_config field {k!r}")
+        if k not in RECONCILABLE_FIELDS:
+            raise KeyError(f"reconciled constants: {k!r} is not a reconcilable mrf_config field {RECONCILABLE_FIELDS}")
         setattr(cfg, k, type(getattr(cfg, k))(v))
+
+
+def reconciled_constants_source():
+    """None when the recalled defaults are in force, else {"path", "fields", "strings"} of the constants file every
+    planner of this process is built with (surfaced by bench.py's line and FabricHandle.constants_source)."""
+    d = reconciled_constants()
+    if not d:
+        return None
+    return {"path": os.environ.get("MRF_CONSTANTS") or CONSTANTS_FILE, "fields": dict(d.get("fields", {})),
+            "strings": dict(d.get("strings", {}))}
 
 
 def _library_strings():

@@ -63,6 +63,13 @@ class FabricHandle:
                 self._h = C.c_void_p()
             raise MrfError(f"mrf_create failed: {abi.STATUS_TEXT.get(rc, rc)} {msg}")
 
+    @property
+    def constants_source(self):
+        """The reconciled-constants file in force when planners are built in this process (config.reconciled_constants_source),
+        or None: the recalled defaults."""
+        from . import config
+        return config.reconciled_constants_source()
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.mrf_destroy(self._h)

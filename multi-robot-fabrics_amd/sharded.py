@@ -308,6 +308,8 @@ class ShardedRollout:
             perr = float(t.item())
         N, H, S = cfg.n_robots, cfg.horizon, sr.S
         sb = 8 if cfg.scalar == abi.F64 else 4
+        if transport != "torch":
+            h.comm_destroy()        # the exchange buffers (2 x N x XS x B scalars per rank) go back before the next block
         rate = sum(per_group) * args.steps / elapsed            # every group's scenarios over the slowest rank's time
         per_rank = [c for size in sr.groups for _, c in robot_partition(N, size)]
         return {
@@ -354,7 +356,11 @@ class ShardedRollout:
         per_step = seconds_per_rollout / H
         alg = sb * (28 + 9 * S + 9 * S * (N - 1)) + sb * 23 / H            # per (robot, horizon step)
         hbm = alg * sr.count * B / per_step                                # this rank's rows
+        nrem = N - sr.count                                                # robots of other ranks, per owned robot
         out = {"bound": "xgmi_link" if sr.G > 1 else "hbm",
+               "exchange_bytes_per_row_step": {"read_from_the_local_buffer": XS * sb * nrem,
+                                               "stored_into_peer_buffers": XS * sb * (sr.G - 1),
+                                               "on_chip_partners": sr.count - 1},
                "hbm_algorithmic": {"achieved": hbm / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8.0e12,
                                    "bytes_per_unit": alg},
                "link": {"bytes_per_link_per_step": link_bytes, "achieved": link_bytes / per_step / 1e9, "peak": 153.0,

@@ -28,17 +28,19 @@ def oracle():
 
 
 def pytest_collection_modifyitems(config, items):
-    """The default build carries no float32 kernels (-DMRF_WITH_F32 adds them): test cases parametrized with
-    scalar = abi.F32 are skipped then, and tests that loop over both scalar types ask abi.has_f32() themselves."""
+    """The default build carries neither the float32 kernels (-DMRF_WITH_F32) nor the wave-pair rollout kernel
+    (-DMRF_WITH_WP): test cases parametrized with scalar = abi.F32 / dtype = "f32" / kernel = 3 are skipped then; tests that
+    loop over the variants ask abi.has_f32() / abi.has_wp() themselves, inside the test."""
     from multi_robot_fabrics_amd import abi
     try:
-        have = abi.has_f32()
+        have_f32, have_wp = abi.has_f32(), abi.has_wp()
     except Exception:       # noqa: BLE001 -- no library at collection time: let the tests report that
         return
-    if have:
-        return
-    skip = pytest.mark.skip(reason="library built without float32 kernels (MRF_WITH_F32=1 python __graft_entry__.py)")
+    skip_f32 = pytest.mark.skip(reason="library built without float32 kernels (MRF_WITH_F32=1 python __graft_entry__.py)")
+    skip_wp = pytest.mark.skip(reason="library built without the wave-pair kernel (MRF_WITH_WP=1 python __graft_entry__.py)")
     for item in items:
         params = getattr(getattr(item, "callspec", None), "params", {})
-        if params.get("scalar") == abi.F32 or params.get("dtype") == "f32":
-            item.add_marker(skip)
+        if not have_f32 and (params.get("scalar") == abi.F32 or params.get("dtype") == "f32"):
+            item.add_marker(skip_f32)
+        if not have_wp and params.get("kernel") == 3:
+            item.add_marker(skip_wp)

@@ -315,6 +315,75 @@ def mirrors_as_reference_modules(repo_root):
            compute_x_obsts_dyn_0=kinematics.compute_x_obsts_dyn_0)
 
 
+PATH_FILES = ("multi_robot_fabrics/fabrics_planner/forward_planner_Jointspace.py",
+              "multi_robot_fabrics/fabrics_planner/forward_planner_Cartesian.py", "multi_robot_fabrics/utils/utils.py",
+              "multi_robot_fabrics/utils/utils_apply_fk.py", "examples/example_pandas_Jointspace.py",
+              "examples/example_pandas_cartesian.py", "examples/parameters_manipulators.py",
+              "examples/simulation_environments/urdfs/panda_with_finger.urdf", "poetry.lock")
+# sha256 of those files in the checkout SURVEY.md describes (/root/reference of the build container): the vectors are only
+# a pin of THAT reference if the checkout they were made from holds the same files
+EXPECTED_SHA256 = {
+    "multi_robot_fabrics/fabrics_planner/forward_planner_Jointspace.py":
+        "11ac8abe21043bd566a436428fe55db62c85b1847e0f0912fca9e9eee94210ac",
+    "multi_robot_fabrics/fabrics_planner/forward_planner_Cartesian.py":
+        "73f1dc3fabc3c97a496e84da4e861c67f6eaae87d91099592cf2df533878a3d1",
+    "multi_robot_fabrics/utils/utils.py":
+        "133b282b0cca057add7aa7c84afdda6a514c03af1df4b04bdd174a44598ff733",
+    "multi_robot_fabrics/utils/utils_apply_fk.py":
+        "3cef85a7adc8d3bae221443552f23e161ceea78106f33cc923ade277e4ed950c",
+    "examples/example_pandas_Jointspace.py":
+        "3f3d80a6c00e876d997a2e4e6aff34657b9a46b2fedca018ae14cc28633e87a6",
+    "examples/example_pandas_cartesian.py":
+        "d5d28244832c349bd23fa5b7ef439bfe5287387b0f0c5fe7609dd4db71bd32ad",
+    "examples/parameters_manipulators.py":
+        "db00c45434450fadc74bf1304fdba6fc73dfc4ece969b832572ce9ab3efd5277",
+    "examples/simulation_environments/urdfs/panda_with_finger.urdf":
+        "8c76433a527f530e6d4bed507d8c12d75272a1096f5b434825cd511ce99d6376",
+    "poetry.lock":
+        "19c578057dfe5b04eabd3819b20efad84e4a49e3878168fc0466594b00d17b45",
+}
+
+
+def provenance(ref_root, dry_run):
+    """Which reference the vectors came from: git HEAD of the checkout (if it is one), the lock's content-hash next to the
+    one reference_requirements.txt was generated from, and the sha256 of every reference file on the path.  A checkout whose
+    files differ from the surveyed ones is refused (the hash-pinned environment and SURVEY's file:line citations belong to
+    one revision)."""
+    import hashlib
+    import subprocess
+    out = {"git_head": "unknown", "files": [], "sha256": []}
+    try:
+        out["git_head"] = subprocess.run(["git", "-C", ref_root, "rev-parse", "HEAD"], capture_output=True, text=True,
+                                         timeout=20).stdout.strip() or "unknown"
+    except Exception:       # noqa: BLE001
+        pass
+    bad = []
+    for rel in PATH_FILES:
+        path = os.path.join(ref_root, rel)
+        h = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else "absent"
+        out["files"].append(rel)
+        out["sha256"].append(h)
+        if not dry_run and EXPECTED_SHA256.get(rel) != h:
+            bad.append(rel)
+    lock_hash = req_hash = "unknown"
+    try:
+        import tomli
+        with open(os.path.join(ref_root, "poetry.lock"), "rb") as f:
+            lock_hash = tomli.load(f)["metadata"]["content-hash"]
+    except Exception:       # noqa: BLE001
+        pass
+    with open(os.path.join(HERE, "reference_requirements.txt")) as f:
+        for line in f:
+            if "lock content-hash" in line:
+                req_hash = line.split("lock content-hash")[1].split(";")[0].strip()
+    out["lock_content_hash"], out["requirements_lock_content_hash"] = lock_hash, req_hash
+    if not dry_run and (bad or lock_hash != req_hash):
+        sys.exit("the reference checkout at %s is not the surveyed revision: %s differ%s -- check out the commit whose files "
+                 "match tests/golden/make_reference_golden.py:EXPECTED_SHA256" %
+                 (ref_root, bad or "no file", "" if lock_hash == req_hash else "; poetry.lock content-hash %s != %s" % (lock_hash, req_hash)))
+    return {k: np.array(v) for k, v in out.items()}
+
+
 def main():
     global OUT
     ap = argparse.ArgumentParser()
@@ -348,6 +417,7 @@ def main():
                 GoalComposition=GoalComposition)
     with open(urdf_path) as f:
         urdf = f.read()
+    np.savez(os.path.join(OUT, "reference_provenance.npz"), **provenance(ref_root, args.dry_run_with_mirrors))
     panda_actions(mods, urdf)
     planar_actions(mods, ref_root)
     rollouts(mods, urdf)

@@ -7,7 +7,8 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = np.load(os.path.join(HERE, "golden", "deadlock_sequences.npz"))
-CASES = sorted({k.split("/")[0] for k in GOLD.files})
+CASES = sorted({k.split("/")[0] for k in GOLD.files if not k.startswith("velavg")})
+VELAVG = sorted({k.split("/")[0] for k in GOLD.files if k.startswith("velavg")})
 
 
 def case(name):
@@ -30,6 +31,20 @@ def test_host_mirror_replays_reference_sequences(name):
         assert (dp.i_leader, dp.i_follower) == (c["leader"][t], c["follower"][t])
         assert list(dp.i_robots_dead) == list(c["dead"][t])
         assert dp.time_in_deadlock == c["time_in_deadlock"][t]
+
+
+@pytest.mark.parametrize("name", VELAVG)
+def test_compute_velocity_average_matches_the_reference_method(name):
+    """DP:36-43 through the reference's own method (recorded by make_deadlock_golden.velocity_average_vectors): uniform and
+    mixed dof lists, an all-zero rollout.  The reference sums sqrt(x**2) term by term; the mirror sums |x| per joint."""
+    from multi_robot_fabrics_amd.deadlock import deadlockprevention
+    c = case(name)
+    dof, H = [int(d) for d in c["dof"]], int(c["H"])
+    dp = deadlockprevention(dof, len(dof), H)
+    for k in range(c["qdot"].shape[0]):
+        d = {f"robot_{i}": [list(c["qdot"][k, i, j]) for j in range(n)] for i, n in enumerate(dof)}
+        assert abs(dp.compute_velocity_average(d) - float(c["avg"][k])) <= 1e-14 * max(1.0, abs(float(c["avg"][k])))
+    assert float(c["avg"][0]) == 0.0
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -80,19 +80,30 @@ def test_urdf_forward_kinematics_agrees_with_the_oracle_chain(oracle):
 def test_simulator_joint_indices_behind_the_sphere_offsets():
     order = [str(n) for n in G["urdf_joint_order"]]
     assert order.index("panda_joint8") == 16 and order.index("panda_joint5") == 11      # SIM:232, SIM:240
-    links, offs = config.sphere_offsets_per_link(4)
-    offs = np.array(offs).reshape(8, 4, 3)
-    length = [0.333, 0.2, 0.3164, 0.2, 0.3840, 0.2, 0.088, 0.2]
-    for li in range(8):
-        z_start = length[li] if li % 2 == 0 else length[li] / 2
-        z = -z_start + np.arange(4) * length[li] / 4
-        if li == 7:
-            z[1] = -z_start + 2 * length[li] / 4                                      # SIM:235
-        np.testing.assert_allclose(offs[li, :, 2], z, atol=1e-15)
-    assert offs[7, 1, :2].tolist() == [0.03, 0.03] and offs[7, 2, :2].tolist() == [-0.03, -0.03]   # hand, SIM:232-239
-    assert offs[4, 2, :2].tolist() == [0.0, 0.02] and offs[4, 3, :2].tolist() == [0.0, 0.06]       # link 5, SIM:240-246
-    untouched = [(l, i) for l in range(8) for i in range(4) if (l, i) not in ((7, 1), (7, 2), (4, 2), (4, 3))]
-    assert all(np.abs(offs[l, i, :2]).max() == 0.0 for l, i in untouched)
+
+
+@pytest.mark.parametrize("n_robots", [2, 3])
+@pytest.mark.parametrize("per_link", [1, 2, 3, 4])
+def test_sphere_offsets_are_what_the_reference_generator_produces(per_link, n_robots):
+    """SURVEY row f2 pinned by the reference's OWN generator: tests/golden/sphere_offsets.npz holds what
+    create_manipulators_simulation.add_collision_spheres (SIM:176-257), compiled from the reference's file and run against a
+    stub simulator, passes to env.add_collision_link for n_obst_per_link = 1..4 and 2 / 3 robots
+    (tests/golden/make_sphere_offsets_golden.py).  config.sphere_offsets_per_link must give the same table."""
+    S = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sphere_offsets.npz"))
+    key = f"n{per_link}_r{n_robots}_"
+    order = [str(n) for n in S["urdf_joint_order"]]
+    assert order == [str(n) for n in G["urdf_joint_order"]]
+    joint_index = [order.index(f"panda_joint{l}") for l in range(1, 9)]         # SIM:202-207: link l <-> URDF joint index
+    links, offs = config.sphere_offsets_per_link(per_link)
+    assert len(links) == 8 * per_link and S[key + "robot"].shape == (n_robots * 8 * per_link,)
+    for robot in range(n_robots):                                               # every robot gets the same table
+        sel = S[key + "robot"] == robot
+        assert [joint_index.index(int(i)) + 1 for i in S[key + "link_index"][sel]] == links
+        assert S[key + "sphere_on_link"][sel].tolist() == list(range(per_link)) * 8
+        np.testing.assert_allclose(np.array(offs), S[key + "offset"][sel], rtol=0, atol=1e-15)
+    assert S[key + "rotation_is_identity"].all() and (S[key + "size"] == 0.08).all()   # radius_sphere, PM:23
+    # the method's own return structure holds the same transforms, [robot][link][sphere]
+    np.testing.assert_allclose(S[key + "link_transform_list"][0][:, :, 0:3, 3].reshape(-1, 3), np.array(offs), atol=1e-15)
 
 
 @pytest.mark.parametrize("n", [2, 3])
@@ -148,3 +159,40 @@ def test_reference_requirements_are_the_lock_file():
     sys.path.insert(0, here)
     import make_reference_requirements as gen
     assert gen.render(lock) == text
+
+
+def test_reference_requirements_install_on_the_recipe_platform():
+    """the recipe installs the file with `pip install --require-hashes --no-deps` on python:3.9-slim (Linux).
+    Statically: every requirement that is unconditional there must have a file Linux can use (an sdist, a pure-Python
+    wheel or a manylinux / musllinux wheel), and the packages the lock only requires on macOS / Windows carry a marker that
+    is false on Linux -- in particular the five pyobjc packages, which have macOS wheels and an sdist that only builds there."""
+    import os
+    import re
+    from packaging.markers import Marker
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "reference_requirements.txt")) as f:
+        reqs = [l[:-2].strip() for l in f if re.match(r"^[A-Za-z0-9]", l)]
+    assert len(reqs) == 103
+    env = {"sys_platform": "linux", "python_version": "3.9", "platform_system": "Linux", "os_name": "posix"}
+    cond = {}
+    for r in reqs:
+        name, _, marker = r.partition(";")
+        cond[name.split("==")[0].strip().lower()] = (not marker.strip()) or Marker(marker.strip()).evaluate(env)
+    for n in ("pyobjc-core", "pyobjc-framework-applicationservices", "pyobjc-framework-cocoa", "pyobjc-framework-coretext",
+              "pyobjc-framework-quartz", "colorama", "atomicwrites"):
+        assert cond[n] is False, n                                  # not installed on the recipe's platform
+    for n in ("casadi", "fabrics", "forwardkinematics", "numpy", "evdev", "python-xlib"):
+        assert cond[n] is True, n
+    lock = "/root/reference/poetry.lock"
+    if not os.path.exists(lock):
+        pytest.skip("the reference is not present here (file names come from its lock)")
+    import tomli
+    with open(lock, "rb") as f:
+        pkgs = {p["name"].lower(): p for p in tomli.load(f)["package"]}
+    usable = lambda fn: fn.endswith((".tar.gz", ".zip")) or "-none-any" in fn or "linux" in fn
+    for n, installed in cond.items():
+        files = [x["file"] for x in pkgs[n]["files"]]
+        if installed and not any(usable(fn) for fn in files):
+            raise AssertionError(f"{n} is unconditional on Linux but the lock only has {files[:3]}...")
+        if installed and n.startswith("pyobjc"):
+            raise AssertionError(n)
