@@ -259,11 +259,13 @@ def run_config(name, dtype, device_index, iters=5, warmup=2, check=True):
         bytes_unit = algorithmic_bytes_per_rollout_step(N, S, H, sb)
     elif kind == "rollout_cartesian_coupled":
         launch = lambda: h.rollout_cartesian_coupled(q, qd, prm)
-        # link-origin table or <= 8 spheres per robot: start spheres in the LDS tile; larger tables: obstacle arrays assembled on
-        # the device (mrf_host::cartesian_tile_applies; the on-chip re-derivation is opt-in, profiles/r05_cartc32.json)
+        # link-origin table or <= 8 spheres per robot: start spheres in the LDS tile; larger tables: ONE launch whose prologue
+        # assembles the obstacle arrays of its own rows (k_rollout_carts_panda, round 6; MRF_CART_PUBLISH=1: the two-launch form
+        # of round 5; the on-chip re-derivation stays opt-in, profiles/r05_cartc32.json)
         on_chip = S <= 8 or os.environ.get("MRF_CART_CHUNKED") == "1"
         units, unit_name = rows * H, "rollout-steps"
-        kernel = "k_rollout_cartc_panda" if on_chip else "k_publish_obstacles + k_rollout_cart_panda"
+        kernel = "k_rollout_cartc_panda" if on_chip else (
+            "k_publish_obstacles + k_rollout_cart_panda" if os.environ.get("MRF_CART_PUBLISH") == "1" else "k_rollout_carts_panda")
         bytes_unit = sb * (28 + 7 * M) + sb * 23 / H                              # what the obstacle-array formulation would move
     else:
         sx, sv, _ = h.fk_spheres(q, qd)

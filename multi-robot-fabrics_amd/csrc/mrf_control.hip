@@ -738,6 +738,14 @@ int mrf_rollout_cartesian_coupled(mrf_handle* h, int64_t n_scen, const void* q0,
   char* ox = (char*)h->cart_work;
   char* ov = ox + sb * 3 * (size_t)M * rows;
   char* orad = ov + sb * 3 * (size_t)M * rows;
+  // round 6: one launch -- the rollout kernel assembles its obstacles in its prologue (k_rollout_carts_panda).  The two-launch
+  // form below (k_publish_obstacles + the obstacle-array kernel) stays selectable for A/B: MRF_CART_PUBLISH=1.
+  static const bool two_launches = [] {
+    const char* e = getenv("MRF_CART_PUBLISH");
+    return e && e[0] == '1';
+  }();
+  if (!two_launches && S <= MRF_MAX_SPHERES && N <= 64)
+    return mrf_host::rollout_cartesian_self(h, n_scen, q0, qdot0, params, ox, ov, avg_out, traj_q, traj_qd, stream);
   dim3 block(64), grid((unsigned)((rows + 63) / 64));
   int rc = dispatch_scalar(h, [&](auto t) {
     using T = decltype(t);

@@ -172,6 +172,10 @@ int rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const 
 bool cartesian_tile_applies(const mrf_handle* h);  // rollout_cartesian_tile will take the call (no obstacle work buffer needed)
 int rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
                            void* traj_q, void* traj_qd, void* stream);
+// the coupled Cartesian rollout for sphere tables beyond the LDS-tile forms: ONE launch, obstacle assembly in the kernel's
+// prologue into the work arrays wx / wv [M][3][rows] (mrf_kernels.hip k_rollout_carts_panda)
+int rollout_cartesian_self(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* wx,
+                           void* wv, void* avg_out, void* traj_q, void* traj_qd, void* stream);
 // the joint-space rollout as a pair of waves per row (mrf_rollout_wp.hip); the caller has checked that the form applies
 int rollout_wave_pair(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params, void* avg_out,
                       void* traj_q, void* traj_qd, void* stream);

@@ -706,6 +706,28 @@ __global__ __launch_bounds__(64) void k_rollout_cartc_panda(const DevCfg<T>* __r
 // reference's loop (EXJ:394-412) done on chip: the dynamic obstacles of robot i are the configured spheres of all
 // other robots of its scenario, x from FK, v = J qdot, a = 0 ("currently no acceleration", EXJ:411) or
 // jac_dot*qdot (use_accel).  Same wave layout and LDS exchange as the rollout kernel, no time stepping.
+// Round 6: PERSISTENT over the resident grid with a one-block software prefetch.  The kernel is one
+// solve per row with nothing of its own to hide memory latency behind (one wave per SIMD): the 14 state loads, then the
+// row's parameters read one group at a time where the solve uses them, were 4-6 exposed HBM round trips per wave
+// (SQ_WAIT_ANY 0.23 of the wave cycles, VALU-busy 0.59; profiles/r05_configs_pmc.json).  A workgroup now walks blocks
+// blockIdx.x, blockIdx.x + gridDim.x, ... ; at the top of a block it issues the 29 parameter loads of THIS block (they land
+// during the seven sincos calls, ~900 instructions) and the 14 state loads of its NEXT block (they land during the solve),
+// so that no load is waited for with nothing else to do.  (Prefetching the next block's parameters as well -- 43 values held
+// across the solve -- does not fit: 196-248 B of scratch per lane, 0.204 ms against 0.167 ms on C2; gpurun_out/act_ab.txt.)
+// MEASURED RESULT (C2, 196 608 scenarios, same box, alternating runs; profiles/r06_experiments.json): one-shot kernel of
+// round 5 0.1650 / 0.1641 ms; persistent without any prefetch 0.1621 / 0.1619; this form 0.1642 / 0.1644; this form with the
+// parameters read lazily 0.1681 / 0.1675; + single chain walk 0.1625 / 0.1621; exchange chunks of 6 instead of 4 spheres
+// 0.1662 / 0.1674.  The loads were NOT what the kernel waits for: with every one of them prefetched a block ahead nothing
+// moves.  C2's table (10 offset spheres per robot) takes the generic exchange path, whose rolled sphere walk and chunked
+// folds cost ~13 k instructions per block against ~7 k of a link-origin rollout step; the waits are the scalar-load /
+// LDS / barrier waits inside that path, as in every other kernel of this family.  Kept: persistence (no per-block
+// dispatch), the top-of-block loads, the single walk -- together -2 %.
+template <typename T>
+struct PrmRegs {
+  T v[MRF_NPARAM];
+  __device__ __forceinline__ T operator[](int i) const { return v[i]; }  // every index is a compile-time constant after unrolling
+};
+
 template <typename T, class LS, bool LO>
 __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                         const T* __restrict__ q, const T* __restrict__ qd,
@@ -717,53 +739,99 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
   const int N = cfg.n_robots;
   const int spw = 64 / N;
   const int lane = threadIdx.x;
-  int ls = lane / N;
-  const int li = lane - ls * N;
-  int64_t scen = (int64_t)blockIdx.x * spw + ls;
-  const bool active = ls < spw && scen < n_scen;
-  if (ls >= spw) ls = 0;
-  if (scen >= n_scen || !active) scen = (int64_t)blockIdx.x * spw + ls;
-  if (scen >= n_scen) scen = n_scen - 1;
   const int64_t rows = n_scen * N;
-  const int64_t row = scen * N + li;
-  PandaState<T> R;
-  load_state(rows, row, q, qd, R);
-  PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
-  T qdd[7], act[7];
-  if constexpr (LO) {
-    panda_solve_row<LS, kSingleWalk<LS>>(
-        cfg, cfg.mount[li], R, P,
-        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
-        },
-        qdd, act,
-        [&](const PandaKin<T>& K1) {
-          publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0 && use_accel != 0, cfg.jsign, cfg.lo_merge01,
-                               cfg.lo_merge45);  // EXJ:336-339,411
-          __syncthreads();
-        });
-  } else {
+  const int64_t nblk = (n_scen + spw - 1) / spw;
+  const int ls0 = lane / N;
+  const int li = lane - ls0 * N;
+  // row of this lane in block b: idle tail lanes and the rows past the batch shadow a valid row (no stores)
+  auto locate = [&](int64_t b, int& ls, int64_t& row) {
+    ls = ls0;
+    int64_t scen = b * spw + ls;
+    const bool active = ls < spw && scen < n_scen;
+    if (ls >= spw) ls = 0;
+    if (scen >= n_scen || !active) scen = b * spw + ls;
+    if (scen >= n_scen) scen = n_scen - 1;
+    row = scen * N + li;
+    return active;
+  };
+  T nq[7], nqd[7];
+  auto fetch = [&](int64_t b) {
+    int ls;
+    int64_t row;
+    locate(b, ls, row);
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      xch[(3 * j + 0) * 64 + lane] = R.cq[j];
-      xch[(3 * j + 1) * 64 + lane] = R.sq[j];
-      xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+      nq[j] = q[j * rows + row];
+      nqd[j] = qd[j * rows + row];
     }
-    __syncthreads();
-    panda_solve_row<LS, false>(
-        cfg, cfg.mount[li], R, P,
-        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
-          obstacles_generic_chunked<typename LS::Collision>(cfg, xch, lane, ls, li, N, cfg.mount[li], cfg.dynamic != 0,
-                                                            use_accel ? cfg.jsign : T(0), E, acc);  // EXJ:411 passes zeros
-        },
-        qdd, act);
-  }
-  if (active) {
+  };
+  fetch(blockIdx.x);
+#pragma unroll 1
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int ls;
+    int64_t row;
+    const bool active = locate(blk, ls, row);
+    PandaState<T> R;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      if (qdd_out) qdd_out[j * rows + row] = qdd[j];
-      act_out[j * rows + row] = act[j];
+      R.q[j] = nq[j];
+      R.qd[j] = nqd[j];
     }
+#if defined(MRF_ACTION_PRM_LAZY)
+    PrmView<T> P{prm, rows, row, {T(0), T(0), T(0)}, false};
+#else
+    PrmRegs<T> P;  // this block's parameters: issued now, in flight during the sincos calls below
+#pragma unroll
+    for (int c = 0; c < MRF_NPARAM; ++c) P.v[c] = prm[c * rows + row];
+#endif
+#ifndef MRF_ACTION_NO_PREFETCH
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);  // the NEXT block's state: in flight during this block's solve
+#endif
+    state_sincos(R);
+    T qdd[7], act[7];
+    if constexpr (LO) {
+      panda_solve_row<LS, kSingleWalk<LS>>(
+          cfg, cfg.mount[li], R, P,
+          [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+            obstacles_from_tile<typename LS::Collision>(cfg, xch, ls, li, N, E, acc);
+          },
+          qdd, act,
+          [&](const PandaKin<T>& K1) {
+            __syncthreads();  // the previous block's folds have finished in every lane
+            publish_link_spheres(xch, lane, K1, cfg.dynamic != 0, cfg.dynamic != 0 && use_accel != 0, cfg.jsign, cfg.lo_merge01,
+                                 cfg.lo_merge45);  // EXJ:336-339,411
+            __syncthreads();
+          });
+    } else {
+      __syncthreads();  // the previous block's chunk walks have finished in every lane
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        xch[(3 * j + 0) * 64 + lane] = R.cq[j];
+        xch[(3 * j + 1) * 64 + lane] = R.sq[j];
+        xch[(3 * j + 2) * 64 + lane] = R.qd[j];
+      }
+      __syncthreads();
+      // one-shot solve: the own chain's kinematics stay alive across the chunked exchange (no scratch in this kernel; the
+      // rollout kernels keep the two-phase form there).  C2: 0.1654 -> 0.1622 ms.
+      constexpr bool GEN_SW = kSingleWalk<LS>;
+      panda_solve_row<LS, GEN_SW>(
+          cfg, cfg.mount[li], R, P,
+          [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+            obstacles_generic_chunked<typename LS::Collision>(cfg, xch, lane, ls, li, N, cfg.mount[li], cfg.dynamic != 0,
+                                                              use_accel ? cfg.jsign : T(0), E, acc);  // EXJ:411 passes zeros
+          },
+          qdd, act);
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (qdd_out) qdd_out[j * rows + row] = qdd[j];
+        act_out[j * rows + row] = act[j];
+      }
+    }
+#ifdef MRF_ACTION_NO_PREFETCH
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+#endif
   }
 }
 
@@ -1220,6 +1288,179 @@ __global__ __launch_bounds__(RES ? 64 : 256) MRF_ATTR_CART void k_rollout_cart_p
   if (active) avg_out[r] = sumsq / (T)(H * 7);
 }
 
+// ---------------------------------------------------------------------------- coupled Cartesian rollout, large sphere tables
+// mrf_rollout_cartesian_coupled for tables the LDS-tile forms cannot hold (more than eight spheres per robot: the YAML's
+// n_obst_per_link = 4 -> 32 spheres, EXC:184, panda_config.yaml:8) in ONE launch (round 6).  The obstacles
+// of a robot are the other robots of its scenario at their START states (EXC:330-352, UFK:3-33) -- neighbouring lanes.  In the
+// prologue every lane leaves cos q / sin q / qdot in LDS, re-walks the chains of its scenario's other robots and writes THEIR
+// spheres (x0, v) into its OWN row of the work arrays [M][3][rows] (coalesced; no scatter into other rows, no separate
+// k_publish_obstacles launch, no radius array: a sphere's radius is the table's, staged in LDS once).  The first
+// CARTS_RESIDENT obstacles of the row are then copied into a per-wave LDS tile [m][6][64] and folded from there in every
+// step, the rest streams through the depth-one register pipeline: 6 scalars per streamed obstacle and step instead of 7, 12
+// instead of 10 obstacles resident (f64).  Step order, both modes and the incremental cos / sin as k_rollout_cart_panda.
+// UR (uniform radius): every sphere of the table has the same radius -- the reference's tables do (PM:23, SIM:196) -- so it
+// sits in an SGPR pair; otherwise the radius of obstacle m is a scalar load of the table entry m % S, issued with the
+// obstacle's fetch.  Measured on CARTC32 (2 Pandas x 32 spheres, H = 30, 196 608 scenarios; gpurun_out/carts_ab*.txt):
+// two launches 6.34 ms; this kernel with the radius from an LDS row 6.45 ms (the per-obstacle ds_read shares lgkmcnt with
+// the leaf constants' scalar loads), scalar load 6.23 ms, uniform 6.08 ms; the obstacle-array kernel alone (CART32) 6.16 ms.
+// 4 instead of 12 resident obstacles: +1.6 %; hoisting the leaf constants' scalar loads out of the loop: +2 % (here) and
+// +10 % (k_rollout_cart_panda) -- both left as they are.
+constexpr int CARTS_NV = 6;  // x0[3], v[3]
+#ifndef MRF_CARTS_TILE_BYTES
+#define MRF_CARTS_TILE_BYTES 36864
+#endif
+template <typename T>
+constexpr int CARTS_RESIDENT = MRF_CARTS_TILE_BYTES / (CARTS_NV * 64 * (int)sizeof(T));  // 12 (f64), 24 (f32)
+
+template <typename T, class LS, bool UR>
+__global__ __launch_bounds__(64) void k_rollout_carts_panda(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
+                                                             const T* __restrict__ q0, const T* __restrict__ qd0,
+                                                             const T* __restrict__ prm, T* __restrict__ wx,
+                                                             T* __restrict__ wv, T* __restrict__ avg_out,
+                                                             T* __restrict__ traj_q, T* __restrict__ traj_qd) {
+  constexpr int NRES = CARTS_RESIDENT<T>;
+  __shared__ T res[NRES * CARTS_NV * 64];
+  static_assert(NRES * CARTS_NV >= 21, "the prologue's joint-state rows live in the tile");
+  const DevCfg<T>& cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int N = cfg.n_robots, S = cfg.n_spheres;
+  const int spw = 64 / N;  // scenarios per wave: their rows are contiguous, first row of the block + lane
+  int ls = lane / N;
+  int li = lane - ls * N;
+  const int64_t rows = n_scen * N;
+  RowAddr<T> ra;
+  ra.rows = rows;
+  ra.first = (int64_t)blockIdx.x * spw * N;
+  const bool active = ls < spw && ra.first + lane < rows;
+  if (!active) ls = li = 0;  // idle lanes shadow the block's first row (no stores)
+  ra.off = active ? (uint32_t)lane : 0u;
+  const int64_t r = ra.first + ra.off;
+  PandaState<T> R;
+  load_state(rows, r, q0, qd0, R);
+  PrmViewU<T> P{prm, ra, {T(0), T(0), T(0)}, false};
+  const T* mount_own = cfg.mount[li];
+  const int M = S * (N - 1);
+  const int nres = M < NRES ? M : NRES;
+  // ---- prologue: obstacle assembly (compute_x_obsts_dyn_0, UFK:3-33), every lane for its own row
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    res[(3 * j + 0) * 64 + lane] = R.cq[j];
+    res[(3 * j + 1) * 64 + lane] = R.sq[j];
+    res[(3 * j + 2) * 64 + lane] = R.qd[j];
+  }
+  __syncthreads();
+  {
+    const bool dyn = cfg.dynamic != 0;
+#pragma unroll 1
+    for (int d = 0; d < N - 1; ++d) {
+      const int jr = d < li ? d : d + 1;  // the other robots in increasing order (EXC:336-349)
+      const T* st = res + ls * N + jr;    // that robot's lane of this scenario
+      panda_walk_spheres<false, T>(
+          cfg, cfg.mount[jr],
+          [&](int j, T& c, T& sn, T& qdj) {
+            c = st[(3 * j + 0) * 64];
+            sn = st[(3 * j + 1) * 64];
+            qdj = st[(3 * j + 2) * 64];
+          },
+          [&](int sp, const T* x, const T* v, const T*) {
+            if (!active) return;
+            const int m = d * S + sp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              ra.store(wx, m * 3 + c, x[c]);
+              ra.store(wv, m * 3 + c, dyn ? v[c] : T(0));  // static fabrics: zero obstacle velocities (EXC:336-337)
+            }
+          });
+    }
+  }
+  __syncthreads();  // every lane has finished reading the joint-state rows
+#pragma unroll 1
+  for (int m = 0; m < nres; ++m) {
+    T* dst = res + m * (CARTS_NV * 64) + lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dst[c * 64] = ra.load(wx, m * 3 + c);  // the lane's own stores of a moment ago
+      dst[(3 + c) * 64] = ra.load(wv, m * 3 + c);
+    }
+  }
+  __syncthreads();
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  T sumsq = T(0);
+  const int H = cfg.horizon;
+#pragma unroll 1
+  for (int k = 0; k < H; ++k) {
+    const T tk = to_uniform((T)k * cfg.dt);  // elapsed obstacle time (FPC:448-453: x += dt*v per step)
+    T qdd[7], act[7];
+    panda_solve_row<LS, kCartSingleWalk && kSingleWalk<LS>>(
+        cfg, mount_own, R, P,
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+          int sp_next = 0;  // sphere index of the obstacle fetched next (m % S without a division per obstacle)
+          pipelined_pairs<T, CARTS_NV + 1>(
+              M,
+              [&](int m, T (&buf)[CARTS_NV + 1]) {
+                if (m < nres) {
+                  lds_ptr src = (lds_ptr)(res + m * (CARTS_NV * 64) + lane);
+#pragma unroll
+                  for (int c = 0; c < CARTS_NV; ++c) buf[c] = src[c * 64];
+                } else {
+#pragma unroll
+                  for (int c = 0; c < 3; ++c) {
+                    buf[c] = ra.load(wx, m * 3 + c);
+                    buf[3 + c] = ra.load(wv, m * 3 + c);
+                  }
+                }
+                buf[CARTS_NV] = cfg.sphere_r[UR ? 0 : sp_next];
+                if (!UR && ++sp_next == S) sp_next = 0;
+              },
+              [&](int, T (&buf)[CARTS_NV + 1]) {
+                const T xo[3] = {buf[0] + tk * buf[3], buf[1] + tk * buf[4], buf[2] + tk * buf[5]};
+                const T ao[3] = {T(0), T(0), T(0)};  // FPC:33: zero obstacle accelerations (compile-time: the n.a_o terms vanish)
+                accumulate_obstacle<typename LS::Collision>(cfg, E, xo, buf + 3, ao, buf[CARTS_NV], false, acc);
+              });
+        },
+        qdd, act);
+    // system_step (FPC:77-92); cos q / sin q advance by the angle-sum formula while every |dq| of the wave is small
+    T dq[7];
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (cfg.mode == MRF_MODE_VEL) {
+        R.qd[j] = act[j];
+        dq[j] = cfg.dt * R.qd[j];
+      } else {
+        dq[j] = cfg.dt * R.qd[j] + T(0.5) * cfg.dt * cfg.dt * act[j];
+        R.qd[j] += cfg.dt * act[j];
+      }
+      R.q[j] += dq[j];
+      small = small && (m_abs(dq[j]) < T(0.125));
+      sumsq += R.qd[j] * R.qd[j];
+    }
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T sd, cd;
+        small_sincos(dq[j], sd, cd);
+        const T c = R.cq[j] * cd - R.sq[j] * sd;
+        const T sn = R.sq[j] * cd + R.cq[j] * sd;
+        R.cq[j] = c;
+        R.sq[j] = sn;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    }
+    if (active && traj_q) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) ra.store(traj_q, (int64_t)k * 7 + j, R.q[j]);
+    }
+    if (active && traj_qd) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) ra.store(traj_qd, (int64_t)k * 7 + j, R.qd[j]);
+    }
+  }
+  if (active) avg_out[r] = sumsq / (T)(H * 7);
+}
+
 // ---------------------------------------------------------------------------- sphere kinematics
 template <typename T>
 __global__ __launch_bounds__(64) void k_fk_spheres_panda(const DevCfg<T>* __restrict__ cfgp, int64_t rows,
@@ -1610,6 +1851,25 @@ int mrf_host::rollout_cartesian_tile(mrf_handle* h, int64_t n_scen, const void* 
   });
 }
 
+// mrf_rollout_cartesian_coupled for large sphere tables: obstacle assembly in the rollout kernel's prologue
+// (k_rollout_carts_panda); wx / wv = the handle's work arrays [M][3][rows]
+int mrf_host::rollout_cartesian_self(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
+                                     void* wx, void* wv, void* avg_out, void* traj_q, void* traj_qd, void* stream) {
+  const int spw = 64 / h->cfg.n_robots;
+  const dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+  return dispatch(h, [&](auto t, auto cl) {
+    using T = decltype(t);
+    using LS = decltype(cl);
+    auto go = [&](auto kernel) {
+      return launch(h, kernel, grid, block, (hipStream_t)stream, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q0,
+                    (const T*)qdot0, (const T*)params, (T*)wx, (T*)wv, (T*)avg_out, (T*)traj_q, (T*)traj_qd);
+    };
+    bool uniform = true;  // one radius for the whole table (the reference's tables: PM:23)
+    for (int s = 1; s < h->cfg.n_spheres; ++s) uniform = uniform && h->cfg.sphere_radius[s] == h->cfg.sphere_radius[0];
+    return uniform ? go(mrf::k_rollout_carts_panda<T, LS, true>) : go(mrf::k_rollout_carts_panda<T, LS, false>);
+  });
+}
+
 // mrf_rollout_cartesian_coupled in latency mode (one wave per scenario); 1 = the cooperative form does not apply here
 int mrf_host::rollout_cartesian_coop(mrf_handle* h, int64_t n_scen, const void* q0, const void* qdot0, const void* params,
                                      void* avg_out, void* traj_q, void* traj_qd, void* stream) {
@@ -1810,7 +2070,10 @@ int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scen, const void* q, con
   if (use_coop(h, n_scen))
     return launch_coop<false>(h, n_scen, q, qdot, params, (int)use_accel, nullptr, nullptr, nullptr, qddot_out, action_out, st);
   const int spw = 64 / h->cfg.n_robots;
-  dim3 block(64), grid((unsigned)((n_scen + spw - 1) / spw));
+  // persistent: at most the resident workgroup count (one single-wave workgroup per SIMD, register-bound), each walking
+  // its blocks with the next block's loads in flight (k_action_coupled)
+  const int64_t nblk = (n_scen + spw - 1) / spw, resident = (int64_t)4 * h->n_cus;
+  dim3 block(64), grid((unsigned)(nblk < resident ? nblk : resident));
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);

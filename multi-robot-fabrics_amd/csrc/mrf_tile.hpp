@@ -131,7 +131,10 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
 // per wave), a chunk does.  xch holds cos q, sin q, qdot of every lane ([21][64], the rolled walk reads them by joint
 // index); chunk is the exchange tile.  acc_scale: jsign for x-dot-dot = jac_dot*qdot (rollouts, FPJ:97-99), 0 where the
 // reference passes zero accelerations (EXJ:411).
-constexpr int GEN_CH = 4;
+#ifndef MRF_GEN_CH
+#define MRF_GEN_CH 4  // experiment switch (tools/build_variant.sh): spheres per exchange chunk
+#endif
+constexpr int GEN_CH = MRF_GEN_CH;
 constexpr int GEN_XCH = 21 * 64;
 constexpr int GEN_SCALARS = GEN_XCH + GEN_CH * 9 * 64;
 

@@ -185,7 +185,7 @@ def baseline_config(name, scalar=abi.F64):
               the other robots' start states never leave the chip (LDS tile, k_rollout_cartc_panda)
         CART32 / CARTC32  the reference's DEFAULT Cartesian example (panda_config.yaml: 2 robots, n_obst_per_link: 4 -> 32 spheres
               per robot, EXC:184) at H=30: through obstacle arrays (mrf_rollout_cartesian) and through the coupled entry point,
-              which re-derives the other robot's spheres from its start joint state in every step (obstacles_start_chunked)
+              whose kernel assembles the obstacle arrays of its own rows in its prologue (k_rollout_carts_panda, round 6)
     -> dict(cfg, kind, batch = keyword arguments of panda_batch, scenarios_per_cu_round, label)."""
     if name == "C2":
         cfg = _config.panda_config(n_robots=2, horizon=1, scalar=scalar)
@@ -217,7 +217,7 @@ def baseline_config(name, scalar=abi.F64):
             return dict(cfg=cfg, kind="rollout_cartesian", batch=dict(x_min=0.1),
                         label="2-Panda Cartesian rollout H=30, M=32 (n_obst_per_link=4) through obstacle arrays")
         return dict(cfg=cfg, kind="rollout_cartesian_coupled", batch=dict(x_min=0.1),
-                    label="2-Panda Cartesian rollout H=30 against the other robot's 32 spheres (coupled entry point, on chip)")
+                    label="2-Panda Cartesian rollout H=30 against the other robot's 32 spheres (coupled entry point, one launch)")
     raise KeyError(f"unknown baseline configuration {name!r}: {BASELINE_CONFIGS}")
 
 

@@ -51,9 +51,16 @@ def _audit_fields(roof, link_bytes):
     assert roof["traffic"] is not None and roof["traffic"] > 0 and roof["traffic_key"].startswith("sharded_")
 
 
+def _topology_fields(topo, n_devices=1):
+    """the node as HIP shows it, recorded before the sharded block."""
+    assert topo["n_devices"] == n_devices and topo["status"] == "MRF_OK"
+    assert topo["can_access_peer"] == [[1]] and topo["hops"] == [[0]] and topo["link_type"] == [["same device"]]
+
+
 def test_world_one_robot_sharded_block_carries_the_audit_fields():
-    """The default single-GPU run's secondary block: both transports with a group of one (no link), the measured HBM traffic
-    of their kernels and the link model's prediction for one robot per GPU at this batch."""
+    """The default single-GPU run's secondary block: both transports x both payloads with a group of one (no link), the
+    measured HBM traffic of their kernels, the link model's prediction for one robot per GPU at this batch -- 21 joint-state
+    scalars against 54 sphere scalars per robot -- and the node topology."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
@@ -63,14 +70,28 @@ def test_world_one_robot_sharded_block_carries_the_audit_fields():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["exit_code"] == 0
-    for transport in ("rccl", "peer"):
-        blk = r["robot_sharded"][transport]
-        assert "error" not in blk, blk
-        roof = blk["roofline"]
-        assert roof["bound"] == "hbm" and roof["link"]["bytes_per_link_per_step"] == 0
-        assert abs(roof["link"]["predicted_ms_per_step"] - 6 * 9 * 8 * 2016 / 153e9 * 1e3) < 1e-12    # one robot per GPU
-        assert roof["link"]["measured_ms_per_step"] > 0 and roof["traffic"] > 0
-        assert roof["traffic_key"] == f"sharded_{transport}_f64"
+    assert r["build"] == {"has_f32": False, "has_wp": False, "abi_version": 6} or r["build"]["abi_version"] == 6
+    _topology_fields(r["robot_sharded"]["topology"])
+    pred = {}
+    for exchange, scalars, suffix in (("joints", 21, ""), ("spheres", 54, "_spheres")):
+        for transport in ("rccl", "peer"):
+            blk = r["robot_sharded"][transport + suffix]
+            assert "error" not in blk, blk
+            assert blk["exchange"] == exchange and blk["config"]["exchange_scalars_per_robot"] == scalars
+            assert blk["allgather_bytes_per_rank_per_step"] == 3 * scalars * 8 * 3 * 2016     # 3 robots on the one rank, 3 x the batch
+            roof = blk["roofline"]
+            assert roof["bound"] == "hbm" and roof["link"]["bytes_per_link_per_step"] == 0
+            assert abs(roof["link"]["predicted_ms_per_step"] - scalars * 8 * 3 * 2016 / 153e9 * 1e3) < 1e-12    # one robot per GPU
+            assert roof["link"]["measured_ms_per_step"] > 0 and roof["traffic"] > 0
+            assert roof["traffic_key"] == f"sharded_{transport}_{exchange}_f64"
+            assert blk["parity_vs_fused_kernel"]["ok"], blk["parity_vs_fused_kernel"]
+            comm = blk["ranks"][0]["comm"]
+            assert comm["exchange"] == exchange and comm["exchange_scalars_per_robot"] == scalars
+            if transport == "peer":
+                assert blk["ranks"][0]["peers"] == [{"device": 0, "can_access_peer": 1, "link_type": 0, "hops": 0, "rank": 0,
+                                                    "link": "same device"}]
+            pred[exchange] = roof["link"]["predicted_ms_per_step"]
+    assert pred["spheres"] / pred["joints"] >= 2.5            # the link model's prediction, BASELINE config 4
 
 
 def test_bare_launch_spawns_its_own_ranks():
@@ -101,18 +122,25 @@ def test_bare_launch_spawns_its_own_ranks():
     assert peer["rccl_ranks_seen"] is None
 
 
-def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
-    """bench.py --shard robots over the PEER transport with the two ranks of the robot group sharing the one GPU: the
-    JSON line carries the link / algorithmic-HBM roofline views and the sharded result agrees with the fused kernel."""
+@pytest.mark.parametrize("exchange,scalars", [("joints", 21), ("spheres", 54)])
+def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport(exchange, scalars):
+    """bench.py --shard robots over the PEER transport with the two ranks of the robot group sharing the one GPU, either
+    payload: the JSON line carries the link / algorithmic-HBM roofline views, the payload on the wire, where each rank's
+    mapped peer buffer lives, and the sharded result agrees with the fused kernel."""
     env = dict(os.environ, MRF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="4000")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenarios", "2016",
-           "--shard", "robots", "--transport", "peer"]
+           "--shard", "robots", "--transport", "peer", "--exchange", exchange]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert r["n_gpus"] == 2 and r["transport"] == "peer"
+    assert r["n_gpus"] == 2 and r["transport"] == "peer" and r["exchange"] == exchange
+    assert r["config"]["exchange_scalars_per_robot"] == scalars
+    _topology_fields(r["topology"])
+    for x in r["ranks"]:            # both ranks sit on device 0: the peer's mapped buffer is reported there, zero hops
+        assert [p["device"] for p in x["peers"]] == [0, 0] and x["comm"]["peers_one_hop"] == 0
+        assert x["comm"]["exchange"] == exchange and x["comm"]["exchange_scalars_per_robot"] == scalars
     assert r["config"]["robot_group_ranks"] == 2 and r["config"]["robots_per_rank"] == [2, 1]
     assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]
     # 3 robots on 2 ranks: one group [2] whose ranks carry up to 2 robots -> half the scenarios of a 1-robot-per-rank group
@@ -120,11 +148,14 @@ def test_robot_sharded_bench_two_ranks_one_gpu_peer_transport():
     assert r["config"]["robots_per_rank_all"] == [2, 1]
     assert abs(r["value"] - 1008 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
     # both roofline views at world > 1: the link the exchange crosses and the algorithmic HBM bytes of the exchanged formulation
-    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 2 * 6 * 9 * 1008 * 8
+    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 2 * scalars * 1008 * 8
     assert r["roofline"]["link"]["frac"] > 0 and r["roofline"]["hbm_algorithmic"]["frac"] > 0
     assert r["roofline"]["hbm_algorithmic"]["bytes_per_unit"] > 0
-    assert r["allgather_bytes_per_rank_per_step"] == 2 * 6 * 9 * 1008 * 8
-    _audit_fields(r["roofline"], link_bytes=2 * 6 * 9 * 1008 * 8)
+    assert r["allgather_bytes_per_rank_per_step"] == 2 * scalars * 1008 * 8
+    # rank 0 owns robots 0 and 1: one on-chip partner, one remote robot read from the local buffer, one peer stored into
+    assert r["roofline"]["exchange_bytes_per_row_step"] == {"read_from_the_local_buffer": scalars * 8, "stored_into_peer_buffers": scalars * 8,
+                                                            "on_chip_partners": 1}
+    _audit_fields(r["roofline"], link_bytes=2 * scalars * 1008 * 8)
 
 
 def test_stuck_secondary_block_cannot_take_the_headline_with_it():
@@ -189,8 +220,11 @@ def test_four_ranks_one_gpu_one_robot_per_rank_plus_a_replica():
     assert r["config"]["robots_per_rank_all"] == [1, 1, 1, 3] and r["config"]["robots_per_rank"] == [1, 1, 1]
     assert r["parity_vs_fused_kernel"]["ok"], r["parity_vs_fused_kernel"]            # MAX over all four ranks
     assert abs(r["value"] - (504 + 168) * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-9
-    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 1 * 6 * 9 * 504 * 8
-    _audit_fields(r["roofline"], link_bytes=1 * 6 * 9 * 504 * 8)
+    assert r["exchange"] == "joints"                                                 # the default payload: 21 scalars per robot
+    assert r["roofline"]["bound"] == "xgmi_link" and r["roofline"]["link"]["bytes_per_link_per_step"] == 1 * 21 * 504 * 8
+    assert r["roofline"]["link"]["model"]["spheres_payload_bytes_per_scenario_link_step"] == 432
+    _audit_fields(r["roofline"], link_bytes=1 * 21 * 504 * 8)
+    assert [x["comm"]["peers_one_hop"] for x in r["ranks"]] == [0, 0, 0, 0]           # four ranks, one device
 
 
 def test_eight_ranks_one_gpu_default_run_groups_3_3_2():
@@ -214,3 +248,8 @@ def test_eight_ranks_one_gpu_default_run_groups_3_3_2():
     assert peer["config"]["robot_groups"] == [3, 3, 2] and peer["config"]["scenarios_per_group"] == [504, 504, 252]
     assert peer["config"]["robots_per_rank_all"] == [1, 1, 1, 1, 1, 1, 2, 1]
     assert peer["parity_vs_fused_kernel"]["ok"], peer["parity_vs_fused_kernel"]
+    sph = r["robot_sharded"]["peer_spheres"]                 # the sphere payload over the same groups
+    assert "error" not in sph and sph["parity_vs_fused_kernel"]["ok"], sph
+    assert (peer["exchange"], sph["exchange"]) == ("joints", "spheres")
+    assert sph["allgather_bytes_per_rank_per_step"] * 21 == peer["allgather_bytes_per_rank_per_step"] * 54
+    _topology_fields(r["robot_sharded"]["topology"])

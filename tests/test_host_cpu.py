@@ -317,3 +317,30 @@ def test_bench_watchdog_fires_only_when_the_block_overruns():
     assert not fired                                                                              # returned in time
     assert bench.run_guarded(lambda: (time.sleep(0.3), 9)[1], 0.05, lambda: fired.append("late")) == 9
     assert fired == ["late"]                                                                      # overran: guard fired once
+
+
+def test_topology_and_exchange_schema_without_a_gpu():
+    """the fields a first multi-GPU line audits itself with exist whatever the machine -- here, without a
+    device, the topology block reports zero devices and the library's status instead of raising, and the payload arithmetic
+    of the two exchange kinds is what include/mrf.h states (21 joint-state scalars; 9 per exchanged sphere)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.node_topology()
+    assert set(t) >= {"n_devices", "status", "can_access_peer", "link_type", "hops", "visible_devices_env"}, t
+    assert len(t["can_access_peer"]) == len(t["link_type"]) == len(t["hops"]) == min(t["n_devices"], 16)
+    assert set(bench.SHARDED_KEYS) >= {"exchange", "allgather_bytes_per_rank_per_step", "roofline", "ranks", "parity_vs_fused_kernel"}
+    assert abi.COMM_INFO_KEYS[10:] == ("exchange", "exchange_scalars_per_robot", "peers_one_hop") and len(abi.COMM_INFO_KEYS) == 13
+    assert abi.PEER_INFO_KEYS == ("device", "can_access_peer", "link_type", "hops")
+    header = open(os.path.join(ROOT, "include", "mrf.h")).read()
+    assert "#define MRF_COMM_INFO_N 13" in header and "#define MRF_PEER_INFO_N 4" in header
+    assert "#define MRF_JOINT_STATE_SCALARS 21" in header and abi.JOINT_STATE_SCALARS == 21
+    cfg = config.panda_config(n_robots=3, horizon=2)
+    assert cfg.exchange == abi.EXCHANGE_JOINTS                       # the default payload
+    c2 = cfg.copy()
+    c2.exchange = 7
+    out = C.c_void_p()
+    rc = abi.load_library().mrf_create(C.byref(c2), 0, C.byref(out))
+    assert rc == -2 and b"exchange" in abi.load_library().mrf_last_error(out)     # MRF_E_CONFIG, before any device is touched
+    abi.load_library().mrf_destroy(out)

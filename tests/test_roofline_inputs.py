@@ -19,7 +19,7 @@ def test_traffic_json_equals_its_sources():
     for key, rec in tj.items():
         if key.startswith("_") or ("kernel" not in rec and "kernels" not in rec):
             continue                                   # round-1 record kept for history (hand-entered then)
-        if re.fullmatch(r"sharded_(rccl|peer|torch)_(f64|f32)", key):   # robot-sharded transports: bytes per row and step
+        if re.fullmatch(r"sharded_(rccl|peer|torch)_(joints|spheres)_(f64|f32)", key):   # robot-sharded transports: bytes per row and step
             with open(os.path.join(ROOT, rec["source"])) as f:
                 pmc = json.load(f)
             want = make_traffic.sharded_entry(pmc, [k for k in rec["kernels"]], rec["rows"], rec["steps_per_launch"])
@@ -46,10 +46,14 @@ def test_traffic_json_equals_its_sources():
     assert checked >= 5          # the headline and the four configurations of the `configs` block
 
 
-def test_kernel_source_hash_is_of_the_two_kernel_files():
+def test_kernel_source_hash_covers_every_kernel_source():
+    """The stamp covers the files kernels are compiled from: the fused kernels, the device header, the exchange tiles and the
+    robot-sharded kernels (round 6: the latter three files are new)."""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("multi-robot-fabrics_amd/csrc/mrf_kernels.hip", "multi-robot-fabrics_amd/csrc/mrf_device.hpp"):
-        with open(os.path.join(ROOT, rel), "rb") as f:
+    files = ("mrf_kernels.hip", "mrf_device.hpp", "mrf_tile.hpp", "mrf_shard.hpp", "mrf_comm.hip", "mrf_shard_step.hip")
+    for rel in files:
+        with open(os.path.join(ROOT, "multi-robot-fabrics_amd", "csrc", rel), "rb") as f:
             h.update(f.read())
     assert make_traffic.kernel_source_sha256() == h.hexdigest()
+    assert tuple(os.path.basename(p) for p in make_traffic.KERNEL_SOURCES) == files

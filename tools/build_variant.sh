@@ -27,8 +27,12 @@ if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_control.hip" ]; then
   objs="$objs $tmp/c.o"
 fi
 if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_comm.hip" ]; then
-  $hip ${KERNEL_FLAGS--ffast-math} -c -o $tmp/m.o "$src/multi-robot-fabrics_amd/csrc/mrf_comm.hip" &
+  $hip ${KERNEL_FLAGS--ffast-math} "$@" -c -o $tmp/m.o "$src/multi-robot-fabrics_amd/csrc/mrf_comm.hip" &
   objs="$objs $tmp/m.o"
+fi
+if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_shard_step.hip" ]; then
+  $hip ${KERNEL_FLAGS--ffast-math} "$@" -c -o $tmp/s.o "$src/multi-robot-fabrics_amd/csrc/mrf_shard_step.hip" &
+  objs="$objs $tmp/s.o"
 fi
 if [ -f "$src/multi-robot-fabrics_amd/csrc/mrf_hostpath.hip" ]; then
   $hip -c -o $tmp/h.o "$src/multi-robot-fabrics_amd/csrc/mrf_hostpath.hip" &

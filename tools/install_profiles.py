@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 cus = int(sys.argv[sys.argv.index("--cus") + 1]) if "--cus" in sys.argv else 256
 os.chdir(ROOT)
-for name in ("kernel_stats.csv", "pmc.json", "kernels_pmc.json", "per_kernel_f64.json", "configs_pmc.json"):
+for name in ("kernel_stats.csv", "pmc.json", "kernels_pmc.json", "per_kernel_f64.json", "configs_pmc.json",
+             "c32_configs_pmc.json", "shard1_pmc.json"):
     shutil.copy(f"gpurun_out/profiles/{tag}_{name}", f"profiles/{tag}_{name}")
 if os.path.exists("gpurun_out/ex/summary.json"):
     shutil.copy("gpurun_out/ex/summary.json", f"profiles/{tag}_examples.json")
@@ -41,9 +42,16 @@ mt(c, f"config_C3_f64_B{size(2)}", "--horizon", "20", "--kernel-substring", "k_r
 mt(c, f"config_C5_f64_B{size(8)}", "--horizon", "50", "--kernel-substring", "k_rollout_panda<double, LS_reference, false>")
 mt(c, f"config_CART_f64_B{size(3)}", "--horizon", "30", "--kernel-substring", "k_rollout_cart_panda<")
 mt(c, f"config_CARTC_f64_B{size(3)}", "--horizon", "30", "--kernel-substring", "k_rollout_cartc_panda<double, LS_reference, 0>")
+c32 = f"profiles/{tag}_c32_configs_pmc.json"      # the 32-sphere Cartesian shapes: their own pass set (same kernel name as CART)
+mt(c32, f"config_CART32_f64_B{size(2)}", "--horizon", "30", "--kernel-substring", "k_rollout_cart_panda<")
+mt(c32, f"config_CARTC32_f64_B{size(2)}", "--horizon", "30", "--kernel-substring", "k_rollout_carts_panda<")
 k = f"profiles/{tag}_kernels_pmc.json"
-mt(k, "sharded_rccl_f64", "--rows", str(rows), "--sum-kernels", "k_step_predict<", "k_step_action<", "--steps-per-launch", "1")
-mt(k, "sharded_peer_f64", "--rows", str(rows), "--sum-kernels", "k_rollout_peer<", "--steps-per-launch", "30")
+mt(k, "sharded_rccl_spheres_f64", "--rows", str(rows), "--sum-kernels", "k_step_predict<", "k_step_action<", "--steps-per-launch", "1")
+mt(k, "sharded_rccl_joints_f64", "--rows", str(rows), "--sum-kernels", "k_step_predict_joints<", "k_step_action_joints<",
+   "--steps-per-launch", "1")
+# a group of one exchanges nothing: the same persistent kernel (XK_NONE) whatever the configured payload
+mt(k, "sharded_peer_joints_f64", "--rows", str(rows), "--sum-kernels", "k_rollout_peer<", "--steps-per-launch", "30")
+mt(k, "sharded_peer_spheres_f64", "--rows", str(rows), "--sum-kernels", "k_rollout_peer<", "--steps-per-launch", "30")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import make_traffic  # noqa: E402
 tj = json.load(open("profiles/traffic.json"))

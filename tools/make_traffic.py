@@ -21,7 +21,9 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("multi-robot-fabrics_amd/csrc/mrf_kernels.hip", "multi-robot-fabrics_amd/csrc/mrf_device.hpp")
+KERNEL_SOURCES = ("multi-robot-fabrics_amd/csrc/mrf_kernels.hip", "multi-robot-fabrics_amd/csrc/mrf_device.hpp",
+                  "multi-robot-fabrics_amd/csrc/mrf_tile.hpp", "multi-robot-fabrics_amd/csrc/mrf_shard.hpp",
+                  "multi-robot-fabrics_amd/csrc/mrf_comm.hip", "multi-robot-fabrics_amd/csrc/mrf_shard_step.hip")
 
 
 def kernel_source_sha256(root=ROOT):
@@ -67,7 +69,7 @@ def main():
     ap.add_argument("--sum-kernels", nargs="+", default=None, help="sharded_* keys: kernel-name substrings whose bytes add up")
     ap.add_argument("--steps-per-launch", type=int, default=1, help="sharded_* keys: rollout steps one launch covers")
     args = ap.parse_args()
-    ms = re.fullmatch(r"sharded_(rccl|peer|torch)_(f64|f32)", args.key)
+    ms = re.fullmatch(r"sharded_(rccl|peer|torch)_(joints|spheres)_(f64|f32)", args.key)
     if ms:
         # measured HBM bytes per owned row and rollout step of a robot-sharded transport's kernels (sharded.roofline)
         if not (args.rows and args.sum_kernels):

@@ -75,7 +75,16 @@ qq, qqd = q.clone(), qd.clone()
 h.step_predict(B, 0, N, qq, qqd, sph)
 report("k_step_action", timed(lambda: h.step_action(B, 0, N, qq, qd.clone(), prm, sph, ssq)), rows,
        sb * (14 + 29 + 9 * SX * (N - 1) + 8), "rows")
-# the peer transport's persistent kernel with a group of one (all robots on this GPU, spheres through memory)
+# ... and with the joint-state payload (round 6): all robots on this GPU exchange on chip, nothing is re-walked
+jst = torch.empty((N, 21, B), dtype=h.dtype, device="cuda")
+qq = q.clone()
+report("k_step_predict_joints", timed(lambda: h.step_predict_joints(B, 0, N, qq, qqd, jst)), rows, sb * (21 + 21), "rows")
+qq = q.clone()
+h.step_predict_joints(B, 0, N, qq, qqd, jst)
+report("k_step_action_joints (all robots local)", timed(lambda: h.step_action_joints(B, 0, N, qq, qd.clone(), prm, jst, ssq)), rows,
+       sb * (7 + 21 + 29 + 8), "rows")
+# the peer transport's persistent kernel with a group of one (round 6: all robots on this GPU exchange on chip -- the fused
+# kernel's step inside the persistent block loop, staging + commit passes around it)
 from multi_robot_fabrics_amd.sharded import ShardedRollout
 sr = ShardedRollout(cfg, 0, 1, device_index=0, transport="peer", max_scenarios=B)
 report("k_rollout_peer (group of one, H=30)", timed(lambda: sr.rollout(q.clone(), qd.clone(), prm), iters=4), rows * H,
