@@ -78,10 +78,10 @@ def test_world_one_robot_sharded_block_carries_the_audit_fields():
             blk = r["robot_sharded"][transport + suffix]
             assert "error" not in blk, blk
             assert blk["exchange"] == exchange and blk["config"]["exchange_scalars_per_robot"] == scalars
-            assert blk["allgather_bytes_per_rank_per_step"] == 3 * scalars * 8 * 3 * 2016     # 3 robots on the one rank, 3 x the batch
+            assert blk["allgather_bytes_per_rank_per_step"] == 3 * scalars * 8 * 2016     # the 3 robots of the one rank
             roof = blk["roofline"]
             assert roof["bound"] == "hbm" and roof["link"]["bytes_per_link_per_step"] == 0
-            assert abs(roof["link"]["predicted_ms_per_step"] - scalars * 8 * 3 * 2016 / 153e9 * 1e3) < 1e-12    # one robot per GPU
+            assert abs(roof["link"]["predicted_ms_per_step"] - scalars * 8 * 2016 / 153e9 * 1e3) < 1e-12    # one robot per GPU
             assert roof["link"]["measured_ms_per_step"] > 0 and roof["traffic"] > 0
             assert roof["traffic_key"] == f"sharded_{transport}_{exchange}_f64"
             assert blk["parity_vs_fused_kernel"]["ok"], blk["parity_vs_fused_kernel"]

@@ -34,7 +34,10 @@ def test_traffic_json_equals_its_sources():
         hits = [k for k in pmc if k.startswith(rec["kernel"]) and not k.startswith("_")]
         assert len(hits) == 1, (key, hits)
         kernel = hits[0]
-        want = make_traffic.derive(pmc[kernel], rec["horizon"], dtype)
+        want = make_traffic.derive(pmc[kernel], rec["horizon"], dtype, rec.get("work_waves"))
+        if rec.get("work_waves"):       # a persistent kernel: the blocks of work follow from the batch in the key
+            N = {"C2": 2}[mc.group(1)]
+            assert rec["work_waves"] == -(-int(mc.group(3)) // (64 // N)) and pmc[kernel]["SQ_WAVES"] < rec["work_waves"], key
         assert rec["bytes_per_launch"] == want["bytes_per_launch"], key
         assert rec["flops_per_unit"] == want["flops_per_unit"], key
         assert rec["kernel_source_sha256"] == pmc.get("_meta", {}).get("kernel_source_sha256"), key

@@ -24,8 +24,8 @@ tj=$root/gpurun_out/profiles/${tag}_configs_traffic.json
 # keys carry the batch bench.config_sizes gives on THIS device (six whole rounds of resident waves)
 size() { python3 -c "import sys; sys.path.insert(0, '$root'); import torch, bench; print(bench.config_sizes('$1', torch.cuda.get_device_properties(0).multi_processor_count))" 2>/dev/null | tail -1; }
 has() { case " $cfgs " in *" $1 "*) return 0;; esac; return 1; }
-mt() { python3 $root/tools/make_traffic.py $pmc config_$1_${dt}_B$(size $1) --horizon $2 --kernel-substring "$3" --out $tj >> $out/summary.log 2>&1; }
-has C2 && mt C2 1 "k_action_coupled<"
+mt() { python3 $root/tools/make_traffic.py $pmc config_$1_${dt}_B$(size $1) --horizon $2 --kernel-substring "$3" $4 $5 --out $tj >> $out/summary.log 2>&1; }
+has C2 && mt C2 1 "k_action_coupled<" --work-waves $(( $(size C2) / 32 ))   # persistent kernel: blocks of work, not resident waves
 has C3 && mt C3 20 "k_rollout_panda<double, LS_reference, true>"
 has C5 && mt C5 50 "k_rollout_panda<double, LS_reference, false>"
 has CART && mt CART 30 "k_rollout_cart_panda<"

@@ -37,7 +37,8 @@ def size(n_robots, rounds=6):
 rows = json.load(open("gpurun_out/prof_kernels_f64.json"))["scenarios"] * 3
 mt(f"profiles/{tag}_pmc.json", f"rollout_f64_N3_H30_B{size(3)}")
 c = f"profiles/{tag}_configs_pmc.json"
-mt(c, f"config_C2_f64_B{size(2)}", "--horizon", "1", "--kernel-substring", "k_action_coupled<")
+# k_action_coupled is persistent (round 6): its waves walk several blocks each, the work is B / 32 wave-sized blocks
+mt(c, f"config_C2_f64_B{size(2)}", "--horizon", "1", "--kernel-substring", "k_action_coupled<", "--work-waves", str(size(2) // 32))
 mt(c, f"config_C3_f64_B{size(2)}", "--horizon", "20", "--kernel-substring", "k_rollout_panda<double, LS_reference, true>")
 mt(c, f"config_C5_f64_B{size(8)}", "--horizon", "50", "--kernel-substring", "k_rollout_panda<double, LS_reference, false>")
 mt(c, f"config_CART_f64_B{size(3)}", "--horizon", "30", "--kernel-substring", "k_rollout_cart_panda<")

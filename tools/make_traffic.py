@@ -34,12 +34,16 @@ def kernel_source_sha256(root=ROOT):
     return h.hexdigest()
 
 
-def derive(entry, horizon, dtype):
+def derive(entry, horizon, dtype, work_waves=None):
+    """work_waves: wave-sized blocks of rows one launch works on, for PERSISTENT kernels whose waves walk several blocks each
+    (k_action_coupled since round 6: SQ_WAVES is the resident grid, not the amount of work); None: SQ_WAVES."""
     sfx = "F64" if dtype == "f64" else "F32"
     out = {"bytes_per_launch": (2.0 * entry["FETCH_SIZE"] + entry["WRITE_SIZE"]) * 1024.0}
     need = [f"SQ_INSTS_VALU_FMA_{sfx}", f"SQ_INSTS_VALU_MUL_{sfx}", f"SQ_INSTS_VALU_ADD_{sfx}", "SQ_WAVES"]
     if all(k in entry for k in need):
-        out["flops_per_unit"] = (2.0 * entry[need[0]] + entry[need[1]] + entry[need[2]]) / entry["SQ_WAVES"] / horizon
+        out["flops_per_unit"] = (2.0 * entry[need[0]] + entry[need[1]] + entry[need[2]]) / (work_waves or entry["SQ_WAVES"]) / horizon
+    if work_waves:
+        out["work_waves"] = work_waves
     return out
 
 
@@ -68,6 +72,8 @@ def main():
     ap.add_argument("--rows", type=int, default=None, help="sharded_* keys: rows the counted launches worked on")
     ap.add_argument("--sum-kernels", nargs="+", default=None, help="sharded_* keys: kernel-name substrings whose bytes add up")
     ap.add_argument("--steps-per-launch", type=int, default=1, help="sharded_* keys: rollout steps one launch covers")
+    ap.add_argument("--work-waves", type=int, default=None,
+                    help="persistent kernels: wave-sized blocks of rows per launch (replaces SQ_WAVES in flops_per_unit)")
     args = ap.parse_args()
     ms = re.fullmatch(r"sharded_(rccl|peer|torch)_(joints|spheres)_(f64|f32)", args.key)
     if ms:
@@ -101,10 +107,10 @@ def main():
     with open(args.pmc) as f:
         pmc = json.load(f)
     kernel = pick(pmc, args.kernel_substring)
-    rec = derive(pmc[kernel], H, dtype)
+    rec = derive(pmc[kernel], H, dtype, args.work_waves)
     rel = os.path.relpath(os.path.abspath(args.pmc), ROOT)
     rec.update(source=rel, kernel=kernel[:60], horizon=H,
-               flops_source=f"(2*SQ_INSTS_VALU_FMA_{dtype.upper()} + MUL + ADD) / SQ_WAVES / H of {rel}",
+               flops_source=f"(2*SQ_INSTS_VALU_FMA_{dtype.upper()} + MUL + ADD) / {'work_waves' if args.work_waves else 'SQ_WAVES'} / H of {rel}",
                kernel_source_sha256=pmc.get("_meta", {}).get("kernel_source_sha256"))
     tj = {}
     if os.path.exists(args.out):
