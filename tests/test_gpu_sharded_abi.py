@@ -157,3 +157,66 @@ def test_peer_timeout_is_loud_and_recoverable():
     for r in ranks:
         assert r["late_peer"] == {"status_raised": True, "avg_all_nan": True, "state_untouched": True}, r
     assert all(r["err_after_second_reset"] < 1e-9 for r in ranks), ranks
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_virtual_ranks_step_kernels_random_configurations(seed):
+    """The per-step kernels of both payloads under randomised planners, driven for EVERY rank of a group from one process
+    (the gather is a concatenation): random robot counts 2..6 and group sizes, contiguous robot blocks of every shape (all
+    robots local / some local + some remote / one robot per rank), link-origin and offset tables with unequal radii,
+    runtime leaf families, collision-link subsets, static fabrics, RF-CV masks -- against the fused kernel (mrf_rollout) to
+    1e-9.  Covers remote_obstacles_joints (chunks of three staged chains for the link-origin table, one for generic tables),
+    the on-chip exchange between the robots of a rank, and the legacy sphere kernels beside them."""
+    from multi_robot_fabrics_amd import sharded
+    rng = np.random.default_rng(500 + seed)
+    N = int(rng.integers(2, 7))
+    H = int(rng.integers(2, 5))
+    cfg = config.panda_config(n_robots=N, horizon=H, dynamic=int(rng.random() < 0.8))
+    if rng.random() < 0.5:              # runtime leaf families (the generic instantiations)
+        config.set_strings(cfg, collision_geometry=f"-{rng.uniform(0.2, 0.8):.3f} / (x ** {int(rng.integers(2, 5))}) * xdot ** 2",
+                           collision_finsler=f"{rng.uniform(0.005, 0.05):.4f} / (x ** {int(rng.integers(2, 5))}) * (1 - ca.heaviside(xdot)) * xdot ** 2")
+    table = rng.choice(["lo", "lo_unequal", "offsets1", "offsets2", "offsets3"])
+    if table == "lo_unequal":           # link-origin table whose coincident spheres cannot be merged
+        config.set_spheres(cfg, list(range(1, 9)), None, radii=rng.uniform(0.05, 0.08, 8))
+    elif table.startswith("offsets"):
+        links, offs = config.sphere_offsets_per_link(int(table[-1]))
+        config.set_spheres(cfg, links, offs, radii=rng.uniform(0.04, 0.07, len(links)))
+    if rng.random() < 0.3:
+        cfg.ego_link_mask = int(rng.integers(1, 0x40))
+    cfg.goal_estimate_mask = int(rng.integers(0, 1 << N))
+    cfg.n_goals = int(rng.integers(1, 4))
+    B = int(rng.integers(5, 40))
+    batch = scenarios.panda_batch(cfg, B, seed=seed, x_min=0.3 if N > 3 else 0.15, q_spread=0.15 if N > 3 else 0.3)
+    ref = FabricHandle(cfg, 0)
+    t = ref.tensor
+    want_avg, tq, tqd = ref.rollout(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), want_traj=True)
+    G = int(rng.integers(1, N + 1))
+    parts = sharded.robot_partition(N, G)
+    for exchange in (abi.EXCHANGE_JOINTS, abi.EXCHANGE_SPHERES):
+        h = ref
+        S = h.exchange_spheres
+        shape = (21,) if exchange == abi.EXCHANGE_JOINTS else (S, 9)
+        state = []
+        for first, count in parts:
+            rows = np.array([s * N + first + l for s in range(B) for l in range(count)])
+            q, qd, prm = (t(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
+            if (cfg.goal_estimate_mask >> first) & ((1 << count) - 1):
+                prm = h.step_prepare(B, first, count, q, qd, prm)
+            state.append(dict(rows=rows, q=q, qd=qd, prm=prm, ss=torch.zeros((B * count,), dtype=torch.float64, device="cuda")))
+        everybody = torch.zeros((N,) + shape + (B,), dtype=torch.float64, device="cuda")
+        for _ in range(H):
+            for (first, count), st in zip(parts, state):          # every rank predicts, the "gather" is the shared array
+                if exchange == abi.EXCHANGE_JOINTS:
+                    h.step_predict_joints(B, first, count, st["q"], st["qd"], everybody[first:first + count])
+                else:
+                    h.step_predict(B, first, count, st["q"], st["qd"], everybody[first:first + count])
+            for (first, count), st in zip(parts, state):
+                if exchange == abi.EXCHANGE_JOINTS:
+                    h.step_action_joints(B, first, count, st["q"], st["qd"], st["prm"], everybody, st["ss"])
+                else:
+                    h.step_action(B, first, count, st["q"], st["qd"], st["prm"], everybody, st["ss"])
+        torch.cuda.synchronize()
+        for st in state:
+            rows = torch.from_numpy(st["rows"]).cuda()
+            assert rel(st["ss"] / (H * 7), want_avg[rows]) < 1e-9, (seed, N, G, table, exchange)
+            assert rel(st["q"], tq[-1][:, rows]) < 1e-9 and rel(st["qd"], tqd[-1][:, rows]) < 1e-9, (seed, N, G, table, exchange)
