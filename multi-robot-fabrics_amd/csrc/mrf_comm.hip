@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -97,6 +98,27 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
       if (wall_clock64() - t0 > V.timeout_ticks) {
+        // post-mortem of the FIRST wait that ran out on this rank (mrf_comm_status prints it under MRF_PEER_DEBUG): which
+        // block, which peer, which sequence number was expected and what the flag held
+        {
+          int* dbg = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
+          if (atomicCAS(dbg + 1, 0, 1) == 0) {
+            const unsigned long long have = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            dbg[2] = blk;
+            dbg[3] = lane;
+            dbg[4] = (int)(seq & 0x7fffffff);
+            dbg[5] = (int)(have & 0x7fffffff);
+            dbg[6] = (int)blockIdx.x;
+            dbg[7] = (int)gridDim.x;
+#ifdef MRF_PEER_HEARTBEAT
+            const int* pd = reinterpret_cast<const int*>(V.base[lane] + V.off_err);  // the awaited peer's heartbeat, right now
+            dbg[10] = __hip_atomic_load(pd + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            dbg[11] = __hip_atomic_load(pd + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            dbg[13] = __hip_atomic_load(pd + 12, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            dbg[14] = __hip_atomic_load(pd + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+          }
+        }
         // the timeout is the GROUP's: raise the error word of every rank, so that a peer which went on with this
         // rank's (now missing) payload cannot return a finite result either
         for (int g = 0; g < V.G; ++g)
@@ -132,6 +154,17 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   const int lane = threadIdx.x;
   const int nblk = (int)((n_scen + spw - 1) / spw);
   if constexpr (LO) stage_sphere_radii(cfg, xch, lane);  // visible after the first barrier; never overwritten
+#ifdef MRF_PEER_HEARTBEAT
+  if (lane == 0) {  // development aid: how many workgroups of which launch have started (read by mrf_comm_status's post-mortem)
+    int* dbg = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
+    const int tag = (int)(seq0 & 0x7fffffff);
+    if (atomicExch(dbg + 8, tag) != tag) {
+      atomicExch(dbg + 9, 0);
+      atomicExch(dbg + 12, 0);
+    }
+    atomicAdd(dbg + 9, 1);
+  }
+#endif
   // The grid is capped at what is resident at once (host side); a workgroup then walks blocks blockIdx.x,
   // blockIdx.x + gridDim.x, ... in increasing order.  Block X only ever waits for block X of the peers, every workgroup
   // of every rank is resident and visits its blocks in increasing index order, so the wait graph has no cycle whatever
@@ -298,6 +331,9 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   }
   __syncthreads();  // xch is rewritten by the next block of this workgroup
   }
+#ifdef MRF_PEER_HEARTBEAT
+  if (lane == 0) atomicAdd(reinterpret_cast<int*>(V.base[V.grank] + V.off_err) + 12, 1);  // workgroups that have left
+#endif
 }
 
 // After k_rollout_peer (same stream): one thread latches the error word, then every row is committed from that latch --
@@ -305,6 +341,9 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 // so that a caller that forgets mrf_comm_status cannot take the result for a rollout.
 __global__ void k_peer_latch(const int* __restrict__ err, int* __restrict__ latch, int group, int etag) {
   *latch = group > 1 ? (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) : 0;
+#ifdef MRF_PEER_HEARTBEAT
+  atomicAdd(const_cast<int*>(err) + 15, 1);  // latch passes that have run (development aid)
+#endif
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_peer_commit(int64_t rows, const int* __restrict__ latch, const T* __restrict__ q_st,
@@ -768,10 +807,32 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         // several ranks on ONE device (the single-GPU test hook) share its workgroup slots: MRF_PEER_DEVICE_SHARE = number
         // of processes whose peer kernels must be resident together
         if (const char* sh = std::getenv("MRF_PEER_DEVICE_SHARE")) {
+          // k > 1: a TEST layout (several processes on one device).  Measured in round 6 (bench --gpus 2/3 with
+          // MRF_BENCH_SHARE_GPU=1, tools/residency_probe.hip, the post-mortem of mrf_comm_status, a -DMRF_PEER_HEARTBEAT
+          // build): between two BACK-TO-BACK rollouts one process's next peer kernel can already be waiting while another
+          // process has finished its previous kernel and its latch pass but does not get its commit pass / copies / next
+          // kernel dispatched for as long as the waiting kernel spins -- an intermittent deadlock of the shared device's
+          // dispatch, not of the exchange (a single rollout between host synchronisations never shows it; round 5's kernel
+          // shows it too: 2 x 512 workgroups always, 2 x 336 never; this round's LDS-carrying kernel 2 x 256 often, 3 x 128 in
+          // ~1 of 6 runs at 43 008 scenarios, never at the test suite's sizes).  One process alone places all 1 024
+          // workgroups co-resident, registers + LDS + scratch included (tools/residency_probe.hip), and on its own device
+          // nothing of a peer's has to be dispatched while it waits.  Shared devices get a small, fixed share; the block
+          // loop covers the batch.
           const int k = std::atoi(sh);
-          if (k > 1) resident = resident / (unsigned)k ? resident / (unsigned)k : 1u;
+          if (k > 1) {
+            resident = resident / (unsigned)k / 2u;
+            if (resident > 128u) resident = 128u;
+            if (resident < 1u) resident = 1u;
+          }
+        }
+        if (const char* mg = std::getenv("MRF_PEER_MAX_GRID")) {  // test hook: several blocks per workgroup at small batches
+          const int k = std::atoi(mg);
+          if (k >= 1 && (unsigned)k < resident) resident = (unsigned)k;
         }
         dim3 block(64), grid(nblk < resident ? nblk : resident);
+        if (std::getenv("MRF_PEER_DEBUG"))
+          std::fprintf(stderr, "[mrf peer] rank %d/%d: occupancy %d per CU x %d CUs -> resident %u, blocks %u, grid %u\n", c->rank,
+                       c->world, per_cu, cus, resident, nblk, grid.x);
         T* q_st = (T*)c->stage;
         T* qd_st = q_st + 7 * rows;
         T* avg_st = qd_st + 7 * rows;
@@ -837,8 +898,23 @@ int mrf_comm_status(mrf_handle* h) {
   if (c->transport == MRF_TRANSPORT_PEER) {
     int err = 0;
     if (int rc = check_hip(h, hipMemcpy(&err, c->local + c->off_err, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy")) return rc;
-    if (err == (int)c->epoch + 1) return fail(h, MRF_E_LAUNCH, "peer exchange timed out: a rank of the group did not publish its spheres "
-                                          "(different call sequence, a dead peer, or kernels that cannot run concurrently)");
+    if (err == (int)c->epoch + 1) {
+      int dbg[16] = {0};
+      (void)hipMemcpy(dbg, c->local + c->off_err, sizeof(dbg), hipMemcpyDeviceToHost);
+      std::string where;
+#ifdef MRF_PEER_HEARTBEAT
+      where = " [rank " + std::to_string(c->rank) + ": last launch that started had seq0 " + std::to_string(dbg[8]) + ", " +
+              std::to_string(dbg[9]) + " of its workgroups started; host has issued up to seq " + std::to_string((long long)(c->seq & 0x7fffffff)) + "]";
+#endif
+      if (dbg[1])  // this rank's own first wait that ran out (absent when the error came from a peer)
+        where += " [first wait that ran out here: block " + std::to_string(dbg[2]) + " (workgroup " + std::to_string(dbg[6]) + " of " +
+                std::to_string(dbg[7]) + ") waited for rank " + std::to_string(dbg[3]) + ", expected sequence " +
+                std::to_string(dbg[4]) + ", flag held " + std::to_string(dbg[5]) + "; that peer's heartbeat then: launch seq0 " +
+                std::to_string(dbg[10]) + ", " + std::to_string(dbg[11]) + " workgroups started, " + std::to_string(dbg[13]) +
+                " left, commit passes run " + std::to_string(dbg[14]) + "]";
+      return fail(h, MRF_E_LAUNCH, "peer exchange timed out: a rank of the group did not publish its payload "
+                                   "(different call sequence, a dead peer, or kernels that cannot run concurrently)" + where);
+    }
   }
   return MRF_OK;
 }

@@ -259,14 +259,15 @@ class ShardedRollout:
                 dist.barrier()
             torch.cuda.synchronize()
 
+        fresh = lambda t: t.clone()
         for _ in range(args.warmup):
-            sr.rollout(q0.clone(), qd0.clone(), prm)
+            sr.rollout(fresh(q0), fresh(qd0), prm)
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         for _ in range(args.steps):
-            avg = sr.rollout(q0.clone(), qd0.clone(), prm)
+            avg = sr.rollout(fresh(q0), fresh(qd0), prm)
         ev1.record()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -283,6 +284,9 @@ class ShardedRollout:
                 err = str(e)
         if err is None and not bool(torch.isfinite(avg).all()):
             err = "non-finite rollout result"
+        if err:     # every rank's own account (the agreed error below is the first rank's only)
+            import sys
+            print(f"[robot-sharded bench, rank {rank}] {err}", file=sys.stderr, flush=True)
         err = agree_on_error(err, world)
         if err:
             raise RuntimeError(f"robot-sharded rollout ({transport}): {err}")
