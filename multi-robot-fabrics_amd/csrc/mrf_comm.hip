@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -95,7 +96,16 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
   if (lane < V.G && lane != V.grank) {
     const unsigned long long* f = peer_flag(V, V.grank, gen, lane, blk);
     const long long t0 = wall_clock64();
+    // Poll with a back-off: every poll is an uncached system-scope load, and a thousand workgroups polling every ~64 cycles
+    // keep the memory fabric busy enough to delay the very stores they wait for (measured with three ranks on one die,
+    // round 6: 5.2 -> see DESIGN.md section 6) -- and to starve other kernels on the device.  0.4 us between the first polls,
+    // doubling to 3.4 us.
+    int naps = 1;
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+#ifndef MRF_PEER_NO_BACKOFF
+      for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
+      if (naps < 8) naps *= 2;
+#endif
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
       if (wall_clock64() - t0 > V.timeout_ticks) {
         // post-mortem of the FIRST wait that ran out on this rank (mrf_comm_status prints it under MRF_PEER_DEBUG): which
@@ -125,7 +135,9 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
           __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
+#ifdef MRF_PEER_NO_BACKOFF
       __builtin_amdgcn_s_sleep(1);
+#endif
     }
   }
   __syncthreads();
@@ -820,8 +832,7 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
           // loop covers the batch.
           const int k = std::atoi(sh);
           if (k > 1) {
-            resident = resident / (unsigned)k / 2u;
-            if (resident > 128u) resident = 128u;
+            resident = resident / (unsigned)k * 3u / 4u;
             if (resident < 1u) resident = 1u;
           }
         }
@@ -830,9 +841,13 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
           if (k >= 1 && (unsigned)k < resident) resident = (unsigned)k;
         }
         dim3 block(64), grid(nblk < resident ? nblk : resident);
-        if (std::getenv("MRF_PEER_DEBUG"))
-          std::fprintf(stderr, "[mrf peer] rank %d/%d: occupancy %d per CU x %d CUs -> resident %u, blocks %u, grid %u\n", c->rank,
-                       c->world, per_cu, cus, resident, nblk, grid.x);
+        if (std::getenv("MRF_PEER_DEBUG")) {
+          timespec ts;
+          clock_gettime(CLOCK_REALTIME, &ts);
+          std::fprintf(stderr, "[mrf peer %ld.%03ld] rank %d/%d: occupancy %d per CU x %d CUs -> resident %u, blocks %u, grid %u, seq0 %llu\n",
+                       (long)(ts.tv_sec % 1000), ts.tv_nsec / 1000000, c->rank, c->world, per_cu, cus, resident, nblk, grid.x,
+                       (unsigned long long)(seq0 & 0x7fffffff));
+        }
         T* q_st = (T*)c->stage;
         T* qd_st = q_st + 7 * rows;
         T* avg_st = qd_st + 7 * rows;
@@ -843,8 +858,15 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         if (int rc = launch(h, mrf::k_peer_latch, dim3(1), dim3(1), st, (const int*)(c->local + c->off_err), latch, c->world,
                             (int)(seq0 >> 40) + 1))
           return rc;
-        return launch(h, mrf::k_peer_commit<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, rows, (const int*)latch,
-                      (const T*)q_st, (const T*)qd_st, (const T*)avg_st, (T*)q_io, (T*)qdot_io, (T*)avg_vel_out);
+        const int rc3 = launch(h, mrf::k_peer_commit<T>, dim3((unsigned)((rows + 255) / 256)), dim3(256), st, rows, (const int*)latch,
+                               (const T*)q_st, (const T*)qd_st, (const T*)avg_st, (T*)q_io, (T*)qdot_io, (T*)avg_vel_out);
+        if (std::getenv("MRF_PEER_DEBUG")) {
+          timespec ts;
+          clock_gettime(CLOCK_REALTIME, &ts);
+          std::fprintf(stderr, "[mrf peer %ld.%03ld] rank %d: the three launches of seq0 %llu are queued\n", (long)(ts.tv_sec % 1000),
+                       ts.tv_nsec / 1000000, c->rank, (unsigned long long)(seq0 & 0x7fffffff));
+        }
+        return rc3;
       };
       // what the robots of other ranks send: nothing (a group of one: the fused kernel's step), joint states, spheres
       if (c->world == 1) return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_NONE>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_NONE>);
@@ -912,6 +934,11 @@ int mrf_comm_status(mrf_handle* h) {
                 std::to_string(dbg[4]) + ", flag held " + std::to_string(dbg[5]) + "; that peer's heartbeat then: launch seq0 " +
                 std::to_string(dbg[10]) + ", " + std::to_string(dbg[11]) + " workgroups started, " + std::to_string(dbg[13]) +
                 " left, commit passes run " + std::to_string(dbg[14]) + "]";
+      if (std::getenv("MRF_PEER_DEBUG")) {
+        timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        std::fprintf(stderr, "[mrf peer %ld.%03ld] rank %d: status sees the time-out\n", (long)(ts.tv_sec % 1000), ts.tv_nsec / 1000000, c->rank);
+      }
       return fail(h, MRF_E_LAUNCH, "peer exchange timed out: a rank of the group did not publish its payload "
                                    "(different call sequence, a dead peer, or kernels that cannot run concurrently)" + where);
     }

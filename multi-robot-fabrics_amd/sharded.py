@@ -260,14 +260,29 @@ class ShardedRollout:
             torch.cuda.synchronize()
 
         fresh = lambda t: t.clone()
+        # Several ranks on ONE device (the single-GPU test layout): every rollout starts from a device synchronisation and a
+        # barrier with NOTHING queued in front of its peer kernel.  Measured in round 6: with the other ranks' peer kernels already
+        # waiting on the shared device, a small kernel (a copy) that one rank still has to run before its own peer kernel can
+        # be held back for seconds -- 2.6 s once, past the 5 s time-out in most runs at 3 x 43 008 scenarios; with no such kernel
+        # in front, 5 of 5 runs pass (DESIGN.md section 6 "Residency").  One rank per device -- any real run -- queues its
+        # rollouts back to back with their copies.
+        shared_device = os.environ.get("MRF_BENCH_SHARE_GPU") == "1" and world > 1
+
+        def one_rollout():
+            qi, qdi = fresh(q0), fresh(qd0)
+            if shared_device:
+                torch.cuda.synchronize()
+                dist.barrier()
+            return sr.rollout(qi, qdi, prm)
+
         for _ in range(args.warmup):
-            sr.rollout(fresh(q0), fresh(qd0), prm)
+            one_rollout()
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         for _ in range(args.steps):
-            avg = sr.rollout(fresh(q0), fresh(qd0), prm)
+            avg = one_rollout()
         ev1.record()
         barrier()
         elapsed = time.perf_counter() - t0

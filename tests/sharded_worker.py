@@ -48,6 +48,8 @@ def main():
     errs = []
     for rep in range(3):        # repeated calls: the flag sequence numbers keep counting across rollouts
         qq, qqd = q.clone(), qd.clone()
+        torch.cuda.synchronize()
+        dist.barrier()          # ranks sharing ONE device: nothing is queued in front of a peer kernel while the others' already wait
         avg = sr.rollout(qq, qqd, prm)
         h.comm_status()
         e = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
