@@ -375,12 +375,14 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
         for transport in (("peer",) if os.environ.get("MRF_BENCH_SHARE_GPU") == "1" else ("rccl", "peer")):
             a.transport = transport
             key = transport + suffix
+            t_leg = time.monotonic()
             try:
                 r = ShardedRollout.bench(cfg, batch, a, rank, world, local_rank)
                 out[key] = {k: r[k] for k in SHARDED_KEYS}
                 out[key]["config"] = r["config"]
             except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
-                out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:900]}
+            out[key]["leg_seconds"] = round(time.monotonic() - t_leg, 2)      # setup + warm-up + timed rollouts + parity check
     return out
 
 
@@ -714,7 +716,7 @@ def main():
         if world == 1:
             sharded_block = robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank)
         else:
-            guard_s = float(os.environ.get("MRF_BENCH_SHARD_TIMEOUT_S", "240"))
+            guard_s = float(os.environ.get("MRF_BENCH_SHARD_TIMEOUT_S", "420"))      # four legs since round 6 (two transports x two payloads)
             sharded_block, clean = robot_sharded_in_children(args, rank, world, guard_s)
             if not clean:
                 exit_code = SHARD_TIMEOUT_RC     # every rank: the run is NOT clean (spawn_ranks / the tests know this code)

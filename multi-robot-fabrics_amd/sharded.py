@@ -96,6 +96,17 @@ def device_identity(device_index):
     return {"name": props.name, "uuid": str(getattr(props, "uuid", "")), "index": int(device_index)}
 
 
+_GROUPS = {}     # ranks tuple -> process group: the bench builds four ShardedRollout objects in a row (two transports x two
+                 # payloads) over the same robot groups; a communicator per group is made once (every rank asks in the same order)
+
+
+def _group_of(ranks):
+    key = (id(dist.distributed_c10d._get_default_group()), ranks)      # a re-initialised default group starts over
+    if key not in _GROUPS:
+        _GROUPS[key] = dist.new_group(ranks=list(ranks))
+    return _GROUPS[key]
+
+
 class HipStepBackend:
     def __init__(self, cfg, device_index):
         from .runtime import FabricHandle
@@ -144,7 +155,7 @@ class ShardedRollout:
             # one communicator per replica; every rank must take part in every new_group call
             first = 0
             for d, size in enumerate(self.groups):
-                g = dist.new_group(ranks=list(range(first, first + size))) if size > 1 else None
+                g = _group_of(tuple(range(first, first + size))) if size > 1 else None
                 if d == self.replica:
                     self.group = g
                 first += size

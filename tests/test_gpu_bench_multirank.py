@@ -199,7 +199,7 @@ def test_faulting_secondary_block_cannot_take_the_headline_with_it():
     assert r["exit_code"] == 3
     assert "rank 1's child: killed by signal 6" in r["robot_sharded"]["error"], r["robot_sharded"]
     assert r["robot_sharded"]["children"][1] == "killed by signal 6"
-    assert took < 200, took         # the surviving child was ended by the flag, not by the 240 s guard
+    assert took < 200, took         # the surviving child was ended by the flag, not by the 420 s guard
 
 
 def test_four_ranks_one_gpu_one_robot_per_rank_plus_a_replica():
