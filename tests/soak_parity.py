@@ -76,7 +76,8 @@ def main():
     from multi_robot_fabrics_amd.runtime import FabricHandle
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first_seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    worst = {"rollout": 0.0, "action": 0.0, "rollout_near_or_through_a_barrier": 0.0, "sharded_peer": 0.0, "sharded_rccl": 0.0}
+    worst = {"rollout": 0.0, "action": 0.0, "rollout_near_or_through_a_barrier": 0.0, "sharded_peer": 0.0, "sharded_rccl": 0.0,
+             "virtual_ranks_joints": 0.0, "virtual_ranks_spheres": 0.0}
     CLEAR = 0.05        # rows whose whole trajectory keeps every barrier coordinate above this are judged
     from multi_robot_fabrics_amd.sharded import ShardedRollout
     nonfinite = 0
@@ -105,6 +106,33 @@ def main():
             if sel.any():
                 e = np.abs(g2[:, sel] - want_qd[-1][:, sel]).max() / max(1e-300, np.abs(want_qd[-1][:, sel]).max())
                 worst["sharded_" + transport] = max(worst["sharded_" + transport], float(e))
+        # round 6: every rank of a random robot group driven from this process through the step kernels (local robots on
+        # chip, remote robots re-walked from joint states / read as spheres), both payloads
+        if N > 1:
+            from multi_robot_fabrics_amd import sharded as _sh
+            G = int(np.random.default_rng(seed).integers(2, N + 1))
+            parts = _sh.robot_partition(N, G)
+            for exchange, name in ((abi.EXCHANGE_JOINTS, "virtual_ranks_joints"), (abi.EXCHANGE_SPHERES, "virtual_ranks_spheres")):
+                shape = (21,) if exchange == abi.EXCHANGE_JOINTS else (h.exchange_spheres, 9)
+                state = []
+                for first, count in parts:
+                    rows = np.array([sc * N + first + l for sc in range(B) for l in range(count)])
+                    q3, qd3, p3 = (h.tensor(np.ascontiguousarray(batch[k][:, rows])) for k in ("q", "qdot", "params"))
+                    if (cfg.goal_estimate_mask >> first) & ((1 << count) - 1):
+                        p3 = h.step_prepare(B, first, count, q3, qd3, p3)
+                    state.append((rows, q3, qd3, p3, torch.zeros((B * count,), dtype=torch.float64, device="cuda")))
+                everybody = torch.zeros((N,) + shape + (B,), dtype=torch.float64, device="cuda")
+                for _ in range(cfg.horizon):
+                    for (first, count), (rows, q3, qd3, p3, ss) in zip(parts, state):
+                        (h.step_predict_joints if exchange == abi.EXCHANGE_JOINTS else h.step_predict)(B, first, count, q3, qd3, everybody[first:first + count])
+                    for (first, count), (rows, q3, qd3, p3, ss) in zip(parts, state):
+                        (h.step_action_joints if exchange == abi.EXCHANGE_JOINTS else h.step_action)(B, first, count, q3, qd3, p3, everybody, ss)
+                for rows, q3, qd3, p3, ss in state:
+                    g3 = qd3.cpu().numpy()
+                    sel = (ok & (rowx >= CLEAR))[rows] & np.isfinite(g3).all(0)
+                    if sel.any():
+                        ref = want_qd[-1][:, rows][:, sel]
+                        worst[name] = max(worst[name], float(np.abs(g3[:, sel] - ref).max() / max(1e-300, np.abs(ref).max())))
         sx, sv, sa = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
         ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv if cfg.dynamic else None, None)
         _, want_act = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
