@@ -287,9 +287,18 @@ struct PandaKin {
 // JSTOP < 7: the walk ends at the origin of joint JSTOP (o, vo, ao of that joint are set, its axis is not): the part of
 // the chain a wave that owns only the proximal collision points needs (k_rollout_panda_wp); cq / sq / qd of joints
 // >= JSTOP are not read.
-template <typename T, int JSTOP = 7>
+// emit_link(link, X, Y, Z, o, w, al, vo, ao), link = 1..8 (a compile-time constant at every call after unrolling): called
+// once the frame, origin, angular velocity / acceleration terms of panda_link<link> are complete -- the point at which the
+// rolled walk below emits the spheres attached to that link.  Lets a kernel derive its configured spheres from the SAME
+// walk that feeds its pullbacks (round 6: k_action_coupled on small generic tables) instead of a second, rolled walk.
+struct NoLinkEmit {
+  template <typename T>
+  __device__ __forceinline__ void operator()(int, const T*, const T*, const T*, const T*, const T*, const T*, const T*, const T*) const {}
+};
+
+template <typename T, int JSTOP = 7, class EmitLink = NoLinkEmit>
 __device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, const T (&cq)[7], const T (&sq)[7],
-                                               const T (&qd)[7], PandaKin<T>& K) {
+                                               const T (&qd)[7], PandaKin<T>& K, EmitLink emit_link = EmitLink()) {
   T X[3] = {mount[0], mount[4], mount[8]}, Y[3] = {mount[1], mount[5], mount[9]}, Z[3] = {mount[2], mount[6], mount[10]};
   T o[3] = {mount[3], mount[7], mount[11]};
   T w[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)}, vo[3] = {T(0), T(0), T(0)}, ao[3] = {T(0), T(0), T(0)};
@@ -321,6 +330,7 @@ __device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, cons
         K.v8[k] = vo[k];
         K.a8[k] = ao[k];
       }
+      emit_link(8, X, Y, Z, o, w, al, vo, ao);  // panda_link8: fixed joint, the frame of link 7 moved along its z
       break;
     }
     if (JSTOP < 7 && j == JSTOP) {
@@ -365,6 +375,7 @@ __device__ __forceinline__ void panda_walk_own(const T* __restrict__ mount, cons
       al[k] += qd[j] * wz[k];
       w[k] += qd[j] * Z[k];
     }
+    emit_link(j + 1, X, Y, Z, o, w, al, vo, ao);
   }
 }
 
@@ -1037,14 +1048,14 @@ struct NoPublish {
 // (in AGPRs) instead of re-walking the chain afterwards: ~800 fewer instructions per solve where the loop is light
 // enough not to spill (measured per kernel with -Rpass-analysis: the link-origin tile loop, the HBM obstacle loop);
 // the kernels whose loop walks other robots' chains keep the two-phase form.
-template <class LS, bool SINGLE_WALK, typename T, class PRM, class Obst, class Publish = NoPublish>
+template <class LS, bool SINGLE_WALK, typename T, class PRM, class Obst, class Publish = NoPublish, class EmitLink = NoLinkEmit>
 __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* __restrict__ mount, const PandaState<T>& R,
                                                 const PRM& prm, Obst obstacles, T (&qdd)[7], T (&act)[7],
-                                                Publish publish = Publish()) {
+                                                Publish publish = Publish(), EmitLink emit_link = EmitLink()) {
   if constexpr (SINGLE_WALK) {
     MRF_MARK("integrate");
     PandaKin<T> K;
-    panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K);
+    panda_walk_own<T, 7>(mount, R.cq, R.sq, R.qd, K, emit_link);
     EgoPts<T, NG> E;
     panda_ego_points<LS::Collision::generic>(cfg, K, prm, E);
     MRF_MARK("walk");
@@ -1060,7 +1071,7 @@ __device__ __forceinline__ void panda_solve_row(const DevCfg<T>& cfg, const T* _
   EgoPts<T, NG> E;
   {
     PandaKin<T> K1;
-    panda_walk_own<T>(mount, R.cq, R.sq, R.qd, K1);
+    panda_walk_own<T, 7>(mount, R.cq, R.sq, R.qd, K1, emit_link);
     panda_ego_points<LS::Collision::generic>(cfg, K1, prm, E);
     publish(K1);  // coupled kernels: hand this robot's link states to the other lanes of the scenario
   }

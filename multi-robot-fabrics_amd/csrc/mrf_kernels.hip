@@ -728,14 +728,24 @@ struct PrmRegs {
   __device__ __forceinline__ T operator[](int i) const { return v[i]; }  // every index is a compile-time constant after unrolling
 };
 
-template <typename T, class LS, bool LO>
+// TAB: how the robots of a scenario exchange their spheres -- TAB_LO the link-origin tile, TAB_PACKED (round 6) any table of
+// up to TILE_PACKED_MAX spheres without obstacle accelerations (the reference's call, EXJ:411): the spheres are derived by
+// the solve's OWN unrolled chain walk (emit_link hook), published once as 6 rows each and folded in one pipelined loop -- no
+// rolled sphere walk, no chunk barriers; TAB_GENERIC everything else (chunked exchange).
+enum { TAB_GENERIC = 0, TAB_LO = 1, TAB_PACKED = 2 };
+
+template <typename T, class LS, int TAB>
 __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen,
                                                         const T* __restrict__ q, const T* __restrict__ qd,
                                                         const T* __restrict__ prm, int use_accel,
                                                         T* __restrict__ qdd_out, T* __restrict__ act_out) {
-  __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
+  constexpr bool LO = TAB == TAB_LO;
+  __shared__ T xch[TAB != TAB_GENERIC ? TILE_SCALARS : GEN_SCALARS];
   const DevCfg<T>& cfg = *cfgp;
   if constexpr (LO) stage_sphere_radii(cfg, xch, threadIdx.x);  // visible after the first publish barrier
+  if constexpr (TAB == TAB_PACKED) {
+    if ((int)threadIdx.x < cfg.n_spheres) xch[TILE_RADII + threadIdx.x] = cfg.sphere_r[threadIdx.x];
+  }
   const int N = cfg.n_robots;
   const int spw = 64 / N;
   const int lane = threadIdx.x;
@@ -802,6 +812,15 @@ __global__ __launch_bounds__(64) void k_action_coupled(const DevCfg<T>* __restri
                                  cfg.lo_merge45);  // EXJ:336-339,411
             __syncthreads();
           });
+    } else if constexpr (TAB == TAB_PACKED) {
+      __syncthreads();  // the previous block's folds have finished in every lane
+      panda_solve_row<LS, kSingleWalk<LS>>(
+          cfg, cfg.mount[li], R, P,
+          [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+            obstacles_from_tile_packed<typename LS::Collision>(cfg, xch, ls, li, N, cfg.n_spheres, E, acc);
+          },
+          qdd, act, [&](const PandaKin<T>&) { __syncthreads(); },  // every lane's spheres are in the tile
+          PackedSphereEmit<T>(cfg, xch, lane, cfg.dynamic != 0));
     } else {
       __syncthreads();  // the previous block's chunk walks have finished in every lane
 #pragma unroll
@@ -2077,11 +2096,18 @@ int mrf_compute_action_coupled(mrf_handle* h, int64_t n_scen, const void* q, con
   return dispatch(h, [&](auto t, auto cl) {
     using T = decltype(t);
     using LS = decltype(cl);
-    if (is_link_origin_table(h->cfg))
-      return launch(h, mrf::k_action_coupled<T, LS, true>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
-                    (const T*)q, (const T*)qdot, (const T*)params, (int)use_accel, (T*)qddot_out, (T*)action_out);
-    return launch(h, mrf::k_action_coupled<T, LS, false>, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen,
-                  (const T*)q, (const T*)qdot, (const T*)params, (int)use_accel, (T*)qddot_out, (T*)action_out);
+    auto go = [&](auto kernel) {
+      return launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (const T*)q, (const T*)qdot,
+                    (const T*)params, (int)use_accel, (T*)qddot_out, (T*)action_out);
+    };
+    if (is_link_origin_table(h->cfg)) return go(mrf::k_action_coupled<T, LS, mrf::TAB_LO>);
+    static const bool no_packed = [] {  // A/B switch: MRF_ACTION_PACKED=0 keeps small tables on the chunked exchange
+      const char* e = getenv("MRF_ACTION_PACKED");
+      return e && e[0] == '0';
+    }();
+    if (!use_accel && !no_packed && h->cfg.n_spheres >= 1 && h->cfg.n_spheres <= mrf::TILE_PACKED_MAX)
+      return go(mrf::k_action_coupled<T, LS, mrf::TAB_PACKED>);
+    return go(mrf::k_action_coupled<T, LS, mrf::TAB_GENERIC>);
   });
 }
 

@@ -124,6 +124,98 @@ __device__ __forceinline__ void obstacles_from_tile(const DevCfg<T>& cfg, const 
 }
 
 
+// Small generic tables without obstacle accelerations (round 6): up to TILE_PACKED_MAX spheres per robot as 6 rows each (x, v)
+// in the same [72][64] tile, one radius per sphere behind it -- published ONCE by the solve's own unrolled chain walk
+// (panda_walk_own's emit_link hook), folded in one software-pipelined loop with the accelerations as compile-time zeros.
+constexpr int TILE_PACKED_MAX = 12;  // 12 x 6 rows = the tile's 72 rows; 12 <= the 16 radius / multiplicity slots behind it
+
+template <class CL, typename T>
+__device__ __forceinline__ void obstacles_from_tile_packed(const DevCfg<T>& cfg, const T* __restrict__ tile, int ls, int li,
+                                                           int N, int nsp, const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+  const int M = (N - 1) * nsp;
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  typedef const volatile __attribute__((address_space(3))) T* lds_vptr;
+  auto address = [&](int d, int sp) {
+    int jr = li + 1 + d;
+    if (jr >= N) jr -= N;
+    return (sp * 6) * 64 + ls * N + jr;
+  };
+  T bufA[7], bufB[7];  // x[3], v[3], radius: ping-pong, the loop is unrolled by two
+  {
+    lds_vptr src = (lds_vptr)(tile + address(0, 0));  // volatile: keeps the first fetch out of the loop (obstacles_from_tile)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bufA[k] = src[k * 64];
+    bufA[6] = ((lds_vptr)tile)[TILE_RADII];
+  }
+  int dn = 0, sn = 0;  // (other robot, sphere) of the sphere fetched last
+  auto fetch_next = [&](T (&buf)[7], bool advance) {
+    if (advance) {
+      if (++sn == nsp) {
+        sn = 0;
+        ++dn;
+      }
+    }
+    lds_ptr src = (lds_ptr)(tile + address(dn, sn));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) buf[k] = src[k * 64];
+    buf[6] = ((lds_ptr)tile)[TILE_RADII + sn];
+  };
+  auto fold = [&](T (&buf)[7]) {
+    const T zero[3] = {T(0), T(0), T(0)};  // EXJ:411 "currently no acceleration": the n.a_o terms compile out
+    accumulate_obstacle<CL>(cfg, E, buf, buf + 3, zero, buf[6], false, acc);
+  };
+  int m = 0;
+#pragma unroll 1
+  for (; m + 1 < M; m += 2) {
+    fetch_next(bufB, true);
+    fold(bufA);
+    fetch_next(bufA, m + 2 < M);  // past the end: re-reads the last sphere, never used
+    fold(bufB);
+  }
+  if (m < M) fold(bufA);  // odd count
+}
+
+// The emit_link hook that goes with it: writes the spheres attached to panda_link<link> (table order) into the packed tile
+// rows of this lane.  State (next table entry, prefetched one sphere ahead) lives in the caller.
+template <typename T>
+struct PackedSphereEmit {
+  const DevCfg<T>& cfg;
+  T* __restrict__ tile;
+  int lane, S;
+  bool dyn;
+  int s, link_s;
+  T off[3];
+  __device__ __forceinline__ PackedSphereEmit(const DevCfg<T>& c, T* t, int ln, bool d)
+      : cfg(c), tile(t), lane(ln), S(c.n_spheres), dyn(d), s(0), link_s(c.n_spheres > 0 ? c.sphere_link[0] : 0) {
+    off[0] = c.sphere_off[0][0];
+    off[1] = c.sphere_off[0][1];
+    off[2] = c.sphere_off[0][2];
+  }
+  __device__ __forceinline__ void operator()(int link, const T* X, const T* Y, const T* Z, const T* o, const T* w, const T* al,
+                                             const T* vo, const T* ao) {
+    (void)al;
+    (void)ao;
+    while (s < S && link_s == link) {
+      const T ox = off[0], oy = off[1], oz = off[2];
+      const int s_next = s + 1 < S ? s + 1 : s;
+      link_s = s + 1 < S ? cfg.sphere_link[s_next] : 0;
+      off[0] = cfg.sphere_off[s_next][0];
+      off[1] = cfg.sphere_off[s_next][1];
+      off[2] = cfg.sphere_off[s_next][2];
+      T rr[3], wr[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) rr[k] = ox * X[k] + oy * Y[k] + oz * Z[k];
+      cross3(w, rr, wr);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        tile[(s * 6 + k) * 64 + lane] = o[k] + rr[k];
+        tile[(s * 6 + 3 + k) * 64 + lane] = dyn ? vo[k] + wr[k] : T(0);  // EXJ:336-337
+      }
+      ++s;
+    }
+  }
+};
+
 // Generic sphere tables (offset spheres, any count): every lane walks ITS OWN chain once, emitting its spheres in
 // table order; they are exchanged CH at a time through a [CH][9][64] LDS tile (18 KB in f64) and each lane folds the
 // chunk's spheres of the other robots of its scenario before the walk moves on -- instead of every lane re-walking all
