@@ -334,8 +334,10 @@ int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot
  *   8 HIP device of the handle   9 peer exchange buffers mapped from other ranks (PEER transport after connect)
  *   10 cfg.exchange (mrf_exchange_kind)   11 scalars per robot, scenario and step on the wire (mrf_exchange_scalars)
  *   12 peers whose mapped buffer lies on a device this one reaches in ONE hop (hipExtGetLinkTypeAndHopCount; -1: not
- *      a connected PEER communicator) */
-#define MRF_COMM_INFO_N 13
+ *      a connected PEER communicator)
+ *   13 workgroups of the persistent PEER kernel's footprint found CO-RESIDENT on this device by the roll call of
+ *      mrf_comm_peer_connect -- the cap of that kernel's grid (0: not measured: a group of one, or ranks sharing a device) */
+#define MRF_COMM_INFO_N 14
 int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n);
 int32_t mrf_comm_transport(const mrf_handle* h);
 /* Where the exchange buffers of a connected PEER communicator really are, per rank g of the group: out[g*MRF_PEER_INFO_N + i]

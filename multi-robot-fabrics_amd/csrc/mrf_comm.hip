@@ -348,6 +348,31 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 #endif
 }
 
+// Residency roll call (mrf_comm_peer_connect): single-wave workgroups with the footprint of k_rollout_peer -- the whole
+// register file of a SIMD lane (512), the link-origin exchange tile of LDS -- count themselves in and wait, bounded, until the
+// whole grid has; a workgroup that gives up says so.  The persistent kernel's grid is capped at a size for which nobody gave
+// up: the cap is MEASURED on the device the communicator lives on, not taken from the occupancy API alone.
+__global__ __launch_bounds__(64) void k_peer_roll_call(unsigned* __restrict__ count, unsigned* __restrict__ gave_up,
+                                                        long long timeout_ticks) {
+  __shared__ double lds[TILE_SCALARS];
+  lds[threadIdx.x] = (double)blockIdx.x;
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");            // the kernel holds the architected ...
+  asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");  // ... and the accumulation half of the register file
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(count, 1u);
+    const long long t0 = wall_clock64();
+    bool all_here = false;
+    do {
+      all_here = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x;
+      if (all_here) break;
+      __builtin_amdgcn_s_sleep(8);
+    } while (wall_clock64() - t0 < timeout_ticks);
+    if (!all_here) atomicAdd(gave_up, 1u);
+    if (lds[1] < 0.0) count[2] = 1u;  // keeps the tile allocated
+  }
+}
+
 // After k_rollout_peer (same stream): one thread latches the error word, then every row is committed from that latch --
 // all rows advance, or (a timed-out exchange: some step folded stale payload) none does and the velocity signal is NaN,
 // so that a caller that forgets mrf_comm_status cannot take the result for a rollout.
@@ -478,6 +503,8 @@ struct Comm {
   int nblk_max = 0;
   size_t off_flags = 0, off_err = 0, off_x = 0, bytes = 0;
   void* stage = nullptr;  // peer kernel outputs before the commit: q [7][rows], qdot [7][rows], avg [rows], latch
+  unsigned grid_cap = 0;   // co-resident workgroups measured by the roll call at connect (0: not measured -- a group of one,
+                           // or ranks sharing a device in tests)
   unsigned long long epoch = 0;  // mrf_comm_reset count: the high bits of every sequence number
   unsigned long long seq = 1;
   hipStream_t last_stream = nullptr;
@@ -510,6 +537,29 @@ size_t scalar_bytes(const mrf_handle* h) { return h->cfg.scalar == MRF_F64 ? 8 :
 
 int exchange_scalars(const mrf_handle* h) { return mrf_exchange_scalars(h); }
 bool joints_exchange(const mrf_handle* h) { return h->cfg.exchange == MRF_EXCHANGE_JOINTS; }
+
+// Largest grid of k_peer_roll_call workgroups (<= want) that is co-resident on the handle's device: tried at `want`, then in
+// steps of an eighth less.  ~0.1 ms when the first try holds (a device of its own: tools/residency_probe.hip).
+unsigned measured_coresidency(mrf_handle* h, unsigned want) {
+  unsigned* d = nullptr;
+  if (want < 1u || hipMalloc((void**)&d, 16) != hipSuccess) return 0;
+  int rate_khz = 100000;
+  (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, h->device);
+  unsigned ok = 0;
+  for (unsigned g = want; g >= 1u; g = g * 7u / 8u) {
+    unsigned r[4] = {0, 0, 0, 0};
+    if (hipMemset(d, 0, 16) != hipSuccess) break;
+    hipLaunchKernelGGL(mrf::k_peer_roll_call, dim3(g), dim3(64), 0, nullptr, d, d + 1, (long long)rate_khz * 20);  // 20 ms
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(r, d, 16, hipMemcpyDeviceToHost) != hipSuccess) break;
+    if (r[1] == 0u && r[0] == g) {
+      ok = g;
+      break;
+    }
+    if (g == 1u) break;
+  }
+  (void)hipFree(d);
+  return ok;
+}
 
 int ensure_rccl_buffers(mrf_handle* h, Comm* c, int64_t n_scen) {
   if (n_scen <= c->cap_scen) return MRF_OK;
@@ -628,7 +678,7 @@ int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n) {
       c ? c->transport : MRF_TRANSPORT_NONE, c ? c->rank : 0, c ? c->world : 0, c ? c->first[c->rank] : 0,
       c ? c->first[c->rank + 1] - c->first[c->rank] : 0, c ? c->nccl_count : 0, c ? c->nccl_rank : -1,
       c ? c->nccl_device : -1, h->device, c && c->transport == MRF_TRANSPORT_PEER && c->connected ? c->world - 1 : 0,
-      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop};
+      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop, c ? (int32_t)c->grid_cap : 0};
   for (int i = 0; i < n && i < MRF_COMM_INFO_N; ++i) out[i] = vals[i];
   return MRF_OK;
 }
@@ -691,6 +741,18 @@ int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all) {
     hipError_t e = hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) return fail(h, MRF_E_DEVICE, std::string("hipIpcOpenMemHandle(rank ") + std::to_string(g) + "): " + hipGetErrorString(e));
     c->peer[g] = (unsigned char*)p;
+  }
+  // roll call: how many workgroups of the peer kernel's footprint are co-resident HERE (one process per device; ranks that
+  // share a device in tests take their fixed share instead, mrf_rollout_sharded)
+  const char* share = std::getenv("MRF_PEER_DEVICE_SHARE");
+  const char* force = std::getenv("MRF_PEER_ROLL_CALL");  // "1": run it in the shared-device test layout as well (reported; the
+                                                          // fixed share stays the smaller cap)
+  if (!share || std::atoi(share) <= 1 || (force && force[0] == '1')) {
+    int cus = 256, per_cu = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mrf::k_peer_roll_call, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    c->grid_cap = measured_coresidency(h, (unsigned)per_cu * (unsigned)cus);
+    if (c->grid_cap == 0) return fail(h, MRF_E_DEVICE, "peer transport: the residency roll call could not place a single workgroup");
   }
   c->connected = true;
   return MRF_OK;
@@ -816,20 +878,14 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         unsigned resident = (unsigned)per_cu * (unsigned)cus;
+        if (c->grid_cap && c->grid_cap < resident) resident = c->grid_cap;  // what the roll call at connect found co-resident
         // several ranks on ONE device (the single-GPU test hook) share its workgroup slots: MRF_PEER_DEVICE_SHARE = number
         // of processes whose peer kernels must be resident together
         if (const char* sh = std::getenv("MRF_PEER_DEVICE_SHARE")) {
-          // k > 1: a TEST layout (several processes on one device).  Measured in round 6 (bench --gpus 2/3 with
-          // MRF_BENCH_SHARE_GPU=1, tools/residency_probe.hip, the post-mortem of mrf_comm_status, a -DMRF_PEER_HEARTBEAT
-          // build): between two BACK-TO-BACK rollouts one process's next peer kernel can already be waiting while another
-          // process has finished its previous kernel and its latch pass but does not get its commit pass / copies / next
-          // kernel dispatched for as long as the waiting kernel spins -- an intermittent deadlock of the shared device's
-          // dispatch, not of the exchange (a single rollout between host synchronisations never shows it; round 5's kernel
-          // shows it too: 2 x 512 workgroups always, 2 x 336 never; this round's LDS-carrying kernel 2 x 256 often, 3 x 128 in
-          // ~1 of 6 runs at 43 008 scenarios, never at the test suite's sizes).  One process alone places all 1 024
-          // workgroups co-resident, registers + LDS + scratch included (tools/residency_probe.hip), and on its own device
-          // nothing of a peer's has to be dispatched while it waits.  Shared devices get a small, fixed share; the block
-          // loop covers the batch.
+          // k > 1: a TEST layout (several processes on one device): three quarters of the share.  What round 6 found about
+          // this layout at large batches -- a small kernel in FRONT of a rank's peer kernel is starved while the other
+          // ranks' peer kernels wait on the same device -- is handled where the rollouts are issued (sharded.py, DESIGN.md
+          // section 6 "Residency"), not by the size of the share.
           const int k = std::atoi(sh);
           if (k > 1) {
             resident = resident / (unsigned)k * 3u / 4u;

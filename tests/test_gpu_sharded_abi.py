@@ -84,8 +84,10 @@ def test_comm_argument_errors():
     assert h.comm_partition() == (0, 2)
 
 
-def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port):
+def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port, roll_call=False):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="8000", MRF_PEER_DEVICE_SHARE=str(world))
+    if roll_call:       # the residency roll call of mrf_comm_peer_connect runs although the ranks share the device
+        env["MRF_PEER_ROLL_CALL"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), str(n_robots),
            str(horizon), str(n_scen), table, dtype, exchange]
@@ -99,8 +101,10 @@ def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchan
 @pytest.mark.parametrize("n_robots,horizon,n_scen,table,dtype", [(2, 8, 50, "lo", "f64"), (3, 6, 45, "lo", "f64"),
                                                                   (3, 4, 30, "offsets", "f64"), (2, 6, 40, "lo", "f32")])
 def test_two_processes_one_gpu_peer_exchange(n_robots, horizon, n_scen, table, dtype, exchange):
-    ranks = _run_group_on_one_gpu(2, n_robots, horizon, n_scen, table, dtype, exchange, 29547)
+    ranks = _run_group_on_one_gpu(2, n_robots, horizon, n_scen, table, dtype, exchange, 29547, roll_call=(table == "lo"))
     assert sorted(r["count"] for r in ranks) == sorted([n_robots // 2, n_robots - n_robots // 2])
+    for r in ranks:     # the roll call places between one and 4 x CUs workgroups of the peer kernel's footprint (two processes may
+        assert (0 < r["coresident"] <= 4 * 256) if table == "lo" else r["coresident"] == 0, ranks   # run it at the same moment)
     tol = 1e-9 if dtype == "f64" else 2e-3
     for r in ranks:
         assert r["err"] < tol, ranks
