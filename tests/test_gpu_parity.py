@@ -660,3 +660,37 @@ def test_validate_rejects_an_empty_link_mask():
         FabricHandle(cfg, 0)
     cfg.n_ego = 0               # "grasp" planner: no collision links at all, the mask is not looked at
     FabricHandle(cfg, 0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_coupled_action_packed_tile_random_tables(oracle, seed):
+    """k_action_coupled<TAB_PACKED> (round 6): tables of up to 12 spheres without obstacle accelerations are emitted by the
+    solve's own unrolled chain walk and folded from 6-row tile entries.  Random tables (1..12 spheres drawn from the
+    simulator's 1-3-per-link tables, incl. the hand's x/y-shifted spheres and several spheres on one link, unequal radii),
+    2-5 robots, runtime leaf families and collision-link subsets (the two-walk form), static fabrics, 'acc' and 'vel' --
+    against the oracle fed with the host-side assembly (EXJ:394-412, a = 0 as EXJ:411)."""
+    rng = np.random.default_rng(900 + seed)
+    N = int(rng.integers(2, 6))
+    cfg = config.panda_config(n_robots=N, horizon=1, dynamic=int(rng.random() < 0.8))
+    cfg.kernel_select = 1
+    cfg.mode = int(rng.integers(0, 2))
+    links, offs = config.sphere_offsets_per_link(int(rng.integers(1, 4)))
+    S = int(rng.integers(1, 13))
+    keep = sorted(rng.choice(len(links), size=min(S, len(links)), replace=False).tolist())
+    config.set_spheres(cfg, [links[i] for i in keep], [offs[i] for i in keep], radii=rng.uniform(0.04, 0.08, len(keep)))
+    if rng.random() < 0.5:
+        config.set_strings(cfg, collision_geometry=f"-{rng.uniform(0.2, 0.8):.3f} / (x ** {int(rng.integers(2, 5))}) * xdot ** 2",
+                           collision_finsler=f"{rng.uniform(0.005, 0.05):.4f} / (x ** {int(rng.integers(2, 5))}) * (1 - ca.heaviside(xdot)) * xdot ** 2")
+    if rng.random() < 0.4:
+        cfg.ego_link_mask = int(rng.integers(1, 0x40))
+    cfg.n_goals = int(rng.integers(0, 4))
+    B = int(rng.integers(3, 70))
+    batch = scenarios.panda_batch(cfg, B, seed=seed, x_min=0.3 if N > 3 else 0.15, q_spread=0.15 if N > 3 else 0.3)
+    sx, sv, _ = oracle.fk_spheres(cfg, batch["q"], batch["qdot"])
+    ox, ov, oa, orad = scenarios.other_robot_obstacles(cfg, batch, sx, sv if cfg.dynamic else None, None)
+    want_qdd, want = oracle.compute_action(cfg, batch["q"], batch["qdot"], batch["params"], ox, ov, oa, orad)
+    h = FabricHandle(cfg, 0)
+    act, qdd = h.compute_action_coupled(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]), want_qddot=True)
+    assert relerr(act.cpu().numpy(), want) < F64_RTOL and relerr(qdd.cpu().numpy(), want_qdd) < F64_RTOL, (seed, N, len(keep))
+    again = h.compute_action_coupled(h.tensor(batch["q"]), h.tensor(batch["qdot"]), h.tensor(batch["params"]))
+    assert torch.equal(act, again)
