@@ -326,6 +326,14 @@ int mrf_comm_init(mrf_handle* h, int32_t rank, int32_t world, const void* unique
  * from ipc_handles_all [world][MRF_IPC_HANDLE_BYTES] (rank order; the own entry is not opened). */
 int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_scenarios, void* ipc_handle_out);
 int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all);
+/* The same transport for a group whose ranks live in ONE process (one handle and one stream per rank; the ranks' devices may
+ * differ): instead of IPC handles the ranks exchange the plain device pointers of their exchange buffers --
+ * mrf_comm_peer_local_base() of every rank, then mrf_comm_peer_connect_local(h, bases_all[world]) on every rank (peer access
+ * between different devices is enabled here).  The rollouts of the ranks must be issued on DIFFERENT streams (they wait for
+ * each other on the device) before any of them is synchronised.  Ranks that share a device share its workgroup slots.
+ * Used by the single-process tests of the multi-rank kernels at production grid sizes and by tools/shard_local.py. */
+int mrf_comm_peer_local_base(const mrf_handle* h, void** base_out);
+int mrf_comm_peer_connect_local(mrf_handle* h, void* const* bases_all);
 int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot_count);
 /* What the communicator of this handle is, for logs that must prove what ran (bench.py's robot_sharded block): out[i],
  * i < n <= MRF_COMM_INFO_N:

@@ -83,11 +83,23 @@ __device__ __forceinline__ float quiet_nan<float>() { return __builtin_bit_cast(
 // -- rather than fold it.
 __device__ __forceinline__ void peer_raise_flags(const PeerView& V, int gen, int blk, unsigned long long seq, const int* err,
                                                  int etag, int lane) {
+#ifdef MRF_PEER_HEAVY_FENCE  // round 5's form: a system-scope fence (L2 write-back) and a system-scope release on top
   __threadfence_system();
   __syncthreads();
   const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
   if (lane < V.G && lane != V.grank && !broken)
     __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+  // The payload went out as system-scope (write-through) stores, one instruction per scalar for the whole wave; they are
+  // PERFORMED once the wave's store counter has drained, which is what an agent-scope release waits for -- without the L2
+  // write-back a system-scope fence adds (nothing of the payload sits dirty in L2).  The flag then follows as a relaxed
+  // system-scope store.  Measured with three ranks in one process (tools/shard_local.py, round 6): see DESIGN.md section 6.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
+  if (lane < V.G && lane != V.grank && !broken)
+    __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
 }
 
 // wait for the same workgroup of every other rank (bounded: a missing peer must not hang the GPU)
@@ -101,7 +113,13 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
     // round 6: 5.2 -> see DESIGN.md section 6) -- and to starve other kernels on the device.  0.4 us between the first polls,
     // doubling to 3.4 us.
     int naps = 1;
+#ifdef MRF_PEER_HEAVY_FENCE
     while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+#else
+    // relaxed polls (an acquire per poll invalidates caches a million times per rollout); the payload is read by
+    // system-scope loads after the barrier below
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+#endif
 #ifndef MRF_PEER_NO_BACKOFF
       for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
       if (naps < 8) naps *= 2;
@@ -141,7 +159,11 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
     }
   }
   __syncthreads();
+#ifdef MRF_PEER_HEAVY_FENCE
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every lane reads the peers' payload after the flags
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... by system-scope loads, which no cache of this device answers
+#endif
 }
 
 // q_in / qd_in are only read; the advanced state and the velocity signal go to the STAGING arrays q_st / qd_st / avg_st
@@ -499,6 +521,7 @@ struct Comm {
   unsigned char* local = nullptr;
   unsigned char* peer[MRF_MAX_ROBOTS] = {nullptr};
   bool connected = false;
+  bool in_process = false;  // the peers' buffers are plain device pointers of handles in THIS process (mrf_comm_peer_connect_local)
   int64_t b_max = 0;
   int nblk_max = 0;
   size_t off_flags = 0, off_err = 0, off_x = 0, bytes = 0;
@@ -594,7 +617,7 @@ void mrf_host::comm_release(mrf_handle* h) {
   if (c->sumsq) (void)hipFree(c->sumsq);
   if (c->prm_work) (void)hipFree(c->prm_work);
   for (int g = 0; g < c->world; ++g)
-    if (c->peer[g] && g != c->rank) (void)hipIpcCloseMemHandle(c->peer[g]);
+    if (c->peer[g] && g != c->rank && !c->in_process) (void)hipIpcCloseMemHandle(c->peer[g]);
   if (c->local) (void)hipFree(c->local);
   if (c->stage) (void)hipFree(c->stage);
   delete c;
@@ -758,6 +781,44 @@ int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all) {
   return MRF_OK;
 }
 
+int mrf_comm_peer_local_base(const mrf_handle* h, void** base_out) {
+  if (!h || !base_out) return MRF_E_ARG;
+  const Comm* c = (const Comm*)h->comm;
+  if (!c || c->transport != MRF_TRANSPORT_PEER || !c->local) return MRF_E_ARG;
+  *base_out = c->local;
+  return MRF_OK;
+}
+
+int mrf_comm_peer_connect_local(mrf_handle* h, void* const* bases_all) {
+  MRF_CHECK_READY(h);
+  Comm* c = (Comm*)h->comm;
+  if (!c || c->transport != MRF_TRANSPORT_PEER) return fail(h, MRF_E_ARG, "mrf_comm_peer_open first");
+  if (c->connected) return MRF_OK;
+  if (!bases_all) return fail(h, MRF_E_ARG, "bases missing");
+  for (int g = 0; g < c->world; ++g) {
+    if (g == c->rank) continue;
+    if (!bases_all[g]) return fail(h, MRF_E_ARG, "base of rank " + std::to_string(g) + " missing");
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, bases_all[g]) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(h, MRF_E_ARG, "base of rank " + std::to_string(g) + " is not a device allocation of this process");
+    }
+    if (at.device != h->device) {  // another device of this process: its memory must be reachable from here
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, h->device, at.device);
+      if (!can) return fail(h, MRF_E_DEVICE, "no peer access from device " + std::to_string(h->device) + " to device " + std::to_string(at.device));
+      hipError_t e = hipDeviceEnablePeerAccess(at.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(h, MRF_E_DEVICE, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+    c->peer[g] = (unsigned char*)bases_all[g];
+  }
+  c->in_process = true;
+  c->connected = true;
+  return MRF_OK;
+}
+
 int mrf_comm_peer_info(const mrf_handle* h, int32_t* out, int32_t n) {
   if (!h || !out) return MRF_E_ARG;
   const Comm* c = (const Comm*)h->comm;
@@ -891,6 +952,18 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
             resident = resident / (unsigned)k * 3u / 4u;
             if (resident < 1u) resident = 1u;
           }
+        }
+        if (c->in_process && c->world > 1) {
+          // ranks of an in-process group that share this device run their persistent kernels side by side: each takes its
+          // share of the slots (ranks on other devices of the process do not count)
+          unsigned here = 0;
+          for (int g = 0; g < c->world; ++g) {
+            hipPointerAttribute_t at;
+            std::memset(&at, 0, sizeof(at));
+            if (hipPointerGetAttributes(&at, c->peer[g]) == hipSuccess && at.device == h->device) here += 1;
+          }
+          (void)hipGetLastError();
+          if (here > 1) resident = resident / here ? resident / here : 1u;
         }
         if (const char* mg = std::getenv("MRF_PEER_MAX_GRID")) {  // test hook: several blocks per workgroup at small batches
           const int k = std::atoi(mg);

@@ -408,6 +408,18 @@ class FabricHandle:
         blob = b"".join(handles)
         self._check(self.lib.mrf_comm_peer_connect(self._h, (C.c_ubyte * len(blob)).from_buffer_copy(blob)))
 
+    def comm_peer_local_base(self):
+        """Device pointer (int) of this rank's exchange buffer, for groups whose ranks live in one process."""
+        base = C.c_void_p()
+        if self.lib.mrf_comm_peer_local_base(self._h, C.byref(base)) != 0:
+            raise MrfError("mrf_comm_peer_local_base: comm_peer_open first")
+        return int(base.value)
+
+    def comm_peer_connect_local(self, bases):
+        """PEER transport inside ONE process: `bases` = comm_peer_local_base() of every rank's handle, in rank order."""
+        arr = (C.c_void_p * len(bases))(*[C.c_void_p(b) for b in bases])
+        self._check(self.lib.mrf_comm_peer_connect_local(self._h, arr))
+
     def comm_info(self):
         """What the communicator itself reports (mrf_comm_info): transport, rank, world, robot block, and -- RCCL -- the
         rank count / user rank / device ncclCommCount, ncclCommUserRank and ncclCommCuDevice return."""

@@ -435,3 +435,49 @@ class ShardedRollout:
         except (OSError, ValueError):
             return None
         return dict(e, key=key) if isinstance(e, dict) and "bytes_per_row_step" in e else None
+
+
+class InProcessGroup:
+    """Every rank of ONE robot group inside this process: one FabricHandle and one stream per rank, the exchange buffers
+    connected by their device pointers (mrf_comm_peer_connect_local).  The ranks' persistent peer kernels run side by side
+    on the device(s) of the process and exchange exactly as ranks in separate processes do -- without the dispatch
+    interference several PROCESSES on one device show, so the multi-rank kernels can be tested and
+    timed at production grid sizes on one GPU.  devices: one device index per rank (default: all on device 0)."""
+
+    def __init__(self, cfg, G, max_scenarios, devices=None):
+        from .runtime import FabricHandle
+        self.cfg, self.G, self.N = cfg.copy(), G, cfg.n_robots
+        self.parts = robot_partition(self.N, G)
+        devices = list(devices) if devices is not None else [0] * G
+        self.handles = [FabricHandle(cfg, devices[g]) for g in range(G)]
+        self.streams = [torch.cuda.Stream(device=devices[g]) for g in range(G)]
+        for g, h in enumerate(self.handles):
+            h.comm_peer_open(g, G, max_scenarios)
+        bases = [h.comm_peer_local_base() for h in self.handles]
+        for h in self.handles:
+            h.comm_peer_connect_local(bases)
+            assert h.comm_partition() == self.parts[h.comm_info()["rank"]]
+
+    def own_rows(self, g, n_scen):
+        first, count = self.parts[g]
+        s = torch.arange(n_scen).repeat_interleave(count)
+        r = torch.arange(first, first + count).repeat(n_scen)
+        return s * self.N + r
+
+    def rollout(self, states):
+        """states[g] = (q, qdot, params) of rank g's owned rows; advances q, qdot in place -> [avg_vel of rank g].  All
+        ranks' rollouts are issued (each on its own stream) before anything is waited for."""
+        torch.cuda.synchronize()
+        out = []
+        for h, st, (q, qd, prm) in zip(self.handles, self.streams, states):
+            with torch.cuda.stream(st):
+                out.append(h.rollout_sharded(q, qd, prm, stream=st))
+        for st in self.streams:
+            st.synchronize()
+        for h in self.handles:
+            h.comm_status()
+        return out
+
+    def close(self):
+        for h in self.handles:
+            h.comm_destroy()

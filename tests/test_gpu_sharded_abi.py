@@ -224,3 +224,30 @@ def test_virtual_ranks_step_kernels_random_configurations(seed):
             rows = torch.from_numpy(st["rows"]).cuda()
             assert rel(st["ss"] / (H * 7), want_avg[rows]) < 1e-9, (seed, N, G, table, exchange)
             assert rel(st["q"], tq[-1][:, rows]) < 1e-9 and rel(st["qd"], tqd[-1][:, rows]) < 1e-9, (seed, N, G, table, exchange)
+
+
+@pytest.mark.parametrize("exchange", ["joints", "spheres"])
+@pytest.mark.parametrize("n_robots,G,n_scen,horizon", [(3, 3, 21504, 6), (3, 2, 10752, 5), (4, 4, 8192, 4)])
+def test_in_process_group_at_production_grid_sizes(n_robots, G, n_scen, horizon, exchange):
+    """Every rank of a robot group in THIS process (sharded.InProcessGroup: one handle and one stream per rank, exchange buffers
+    connected by device pointers, mrf_comm_peer_connect_local): the persistent peer kernels of all ranks run side by side
+    with hundreds of workgroups each and SEVERAL blocks per workgroup -- the grid sizes a real run has, which the
+    multi-process tests on one GPU cannot reach reliably (DESIGN.md section 6 "Residency") -- and reproduce the fused kernel."""
+    from multi_robot_fabrics_amd.sharded import InProcessGroup
+    cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+    cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1
+    cfg.exchange = {"joints": abi.EXCHANGE_JOINTS, "spheres": abi.EXCHANGE_SPHERES}[exchange]
+    batch = scenarios.tiled_batch(cfg, n_scen, seed=5, **({"x_min": 0.3, "q_spread": 0.15} if n_robots > 3 else {}))
+    ref = FabricHandle(cfg, 0)
+    want, tq, tqd = ref.rollout(*(ref.tensor(batch[k]) for k in ("q", "qdot", "params")), want_traj=True)
+    grp = InProcessGroup(cfg, G, n_scen)
+    rows = [grp.own_rows(g, n_scen) for g in range(G)]
+    for rep in range(2):        # back to back: the sequence numbers keep counting
+        states = [tuple(ref.tensor(np.ascontiguousarray(batch[k][:, r.numpy()])) for k in ("q", "qdot", "params")) for r in rows]
+        avgs = grp.rollout(states)
+        for g, (avg, r) in enumerate(zip(avgs, rows)):
+            r = r.cuda()
+            assert rel(avg, want[r]) < 1e-9 and rel(states[g][0], tq[-1][:, r]) < 1e-9 and rel(states[g][1], tqd[-1][:, r]) < 1e-9
+    info = grp.handles[0].comm_info()
+    assert info["world"] == G and info["peer_buffers_mapped"] == G - 1 and info["exchange"] == exchange
+    grp.close()

@@ -1,0 +1,88 @@
+"""Every rank of one robot group inside ONE process on ONE GPU (sharded.InProcessGroup): the persistent peer kernels of all
+ranks run side by side, one stream each, and exchange through each other's buffers exactly as separate processes do.  Times
+one rollout of the whole group against the fused kernel on the same scenarios -- the on-die price of the sharded
+formulation at production grid sizes (flag round trips, re-walked remote chains or spheres through memory) -- and checks the
+result.  usage: python tools/shard_local.py [scenarios] [robots] [horizon] [ranks ...]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from multi_robot_fabrics_amd import abi, config, scenarios
+from multi_robot_fabrics_amd.runtime import FabricHandle
+from multi_robot_fabrics_amd.sharded import InProcessGroup
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 43008
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    H = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    groups = [int(a) for a in sys.argv[4:]] or [N]
+    cfg = config.panda_config(n_robots=N, horizon=H)
+    cfg.goal_estimate_mask = ((1 << N) - 1) & ~1
+    batch = scenarios.tiled_batch(cfg, B, seed=77)
+    ref = FabricHandle(cfg, 0)
+    fq, fqd, fprm = (ref.tensor(batch[k]) for k in ("q", "qdot", "params"))
+
+    def timed(fn, iters=5):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters, out
+
+    fused_ms, want = timed(lambda: ref.rollout(fq, fqd, fprm))
+    res = {"scenarios": B, "robots": N, "horizon": H, "fused_ms": fused_ms, "groups": {}}
+    for G in groups:
+        for xname, xk in (("joints", abi.EXCHANGE_JOINTS), ("spheres", abi.EXCHANGE_SPHERES)):
+            c = cfg.copy()
+            c.exchange = xk
+            grp = InProcessGroup(c, G, B)
+            rows = [grp.own_rows(g, B) for g in range(G)]
+            base = [tuple(ref.tensor(np.ascontiguousarray(batch[k][:, r.numpy()])) for k in ("q", "qdot", "params")) for r in rows]
+
+            def one():
+                states = [(q.clone(), qd.clone(), prm) for q, qd, prm in base]
+                return grp.rollout(states)
+
+            import time
+            for _ in range(2):
+                one()
+            t0 = time.perf_counter()
+            iters = 5
+            for _ in range(iters):
+                avgs = one()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            # device time of the slowest rank's own stream for one group rollout (HIP events on the ranks' streams)
+            states = [(q.clone(), qd.clone(), prm) for q, qd, prm in base]
+            torch.cuda.synchronize()
+            evs = []
+            for h, st, (q, qd, prm) in zip(grp.handles, grp.streams, states):
+                with torch.cuda.stream(st):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    h.rollout_sharded(q, qd, prm, stream=st)
+                    e1.record(st)
+                    evs.append((e0, e1))
+            torch.cuda.synchronize()
+            dev_ms = max(a.elapsed_time(b) for a, b in evs)
+            err = max(float((a - want[r.to(a.device)]).abs().max() / want.abs().max()) for a, r in zip(avgs, rows))
+            info = grp.handles[0].comm_info()
+            res["groups"][f"G{G}_{xname}"] = {"ranks": G, "robots_per_rank": [cnt for _, cnt in grp.parts], "exchange": xname,
+                                             "ms_per_group_rollout_wall": ms, "ms_device_slowest_rank": dev_ms, "vs_fused": dev_ms / fused_ms, "rel_err_vs_fused": err,
+                                             "scalars_per_robot": info["exchange_scalars_per_robot"]}
+            grp.close()
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
