@@ -383,7 +383,72 @@ def robot_sharded_block(cfg_roll, batch, args, rank, world, local_rank):
             except Exception as e:      # noqa: BLE001 -- every rank of a group raises together (sharded.py)
                 out[key] = {"error": f"{type(e).__name__}: {e}"[:900]}
             out[key]["leg_seconds"] = round(time.monotonic() - t_leg, 2)      # setup + warm-up + timed rollouts + parity check
+    if world == 1:
+        # ONE ROBOT PER RANK, every rank of the group inside this process on this one GPU (sharded.InProcessGroup): the
+        # persistent peer kernels of N ranks run side by side and exchange through each other's buffers as separate
+        # processes on separate GPUs do -- minus the link.  The on-die price of the north-star partitioning at the bench
+        # batch, and the only multi-rank number a single-GPU run can produce.
+        try:
+            out["one_die_group"] = one_die_group(cfg_roll, batch, a.scenarios // max(1, cfg_roll.n_robots), local_rank,
+                                                 steps=max(1, min(args.steps, 5)))
+        except Exception as e:      # noqa: BLE001
+            out["one_die_group"] = {"error": f"{type(e).__name__}: {e}"[:600]}
     return out
+
+
+def one_die_group(cfg_roll, batch, n_scen, device_index, steps=5):
+    from multi_robot_fabrics_amd import abi
+    from multi_robot_fabrics_amd.runtime import FabricHandle
+    from multi_robot_fabrics_amd.sharded import InProcessGroup
+    N = cfg_roll.n_robots
+    ref = FabricHandle(cfg_roll, device_index)
+    sel = slice(0, n_scen * N)
+    fq, fqd, fprm = (ref.tensor(np.ascontiguousarray(batch[k][:, sel])) for k in ("q", "qdot", "params"))
+    for _ in range(2):
+        want = ref.rollout(fq, fqd, fprm)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        want = ref.rollout(fq, fqd, fprm)
+    e1.record()
+    torch.cuda.synchronize()
+    fused_ms = e0.elapsed_time(e1) / steps
+    res = {"layout": f"{N} ranks x 1 robot in ONE process on one GPU (a handle and a stream per rank, exchange buffers connected by "
+                     "device pointers: mrf_comm_peer_connect_local), the ranks' persistent kernels side by side",
+           "scenarios": n_scen, "fused_kernel_ms_same_scenarios": fused_ms}
+    sb = 8 if cfg_roll.scalar == abi.F64 else 4
+    for xname, xk in (("joints", abi.EXCHANGE_JOINTS), ("spheres", abi.EXCHANGE_SPHERES)):
+        cfg = cfg_roll.copy()
+        cfg.exchange = xk
+        grp = InProcessGroup(cfg, N, n_scen, devices=[device_index] * N)
+        rows = [grp.own_rows(g, n_scen) for g in range(N)]
+        base = [tuple(ref.tensor(np.ascontiguousarray(batch[k][:, sel][:, r.numpy()])) for k in ("q", "qdot", "params")) for r in rows]
+        dev = []
+        for it in range(steps + 1):
+            states = [(q.clone(), qd.clone(), prm) for q, qd, prm in base]
+            torch.cuda.synchronize()
+            evs = []
+            for h, st, (q, qd, prm) in zip(grp.handles, grp.streams, states):
+                with torch.cuda.stream(st):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(st)
+                    avg = h.rollout_sharded(q, qd, prm, stream=st)
+                    b.record(st)
+                    evs.append((a, b, avg))
+            torch.cuda.synchronize()
+            for h in grp.handles:
+                h.comm_status()
+            if it:      # the first one warms up
+                dev.append(max(a.elapsed_time(b) for a, b, _ in evs))
+        err = max(float((avg - want[r.to(avg.device)]).abs().max() / want.abs().max()) for (_, _, avg), r in zip(evs, rows))
+        info = grp.handles[0].comm_info()
+        res[xname] = {"ms_device_slowest_rank": sum(dev) / len(dev), "vs_fused_kernel": sum(dev) / len(dev) / fused_ms,
+                      "parity_vs_fused_kernel": {"max_rel_err": err, "ok": err <= (1e-9 if sb == 8 else 2e-3)},
+                      "bytes_per_rank_pair_per_step": info["exchange_scalars_per_robot"] * n_scen * sb,
+                      "comm_rank0": info}
+        grp.close()
+    return res
 
 
 def robot_sharded_in_children(args, rank, world, guard_s, child_cmd=None):

@@ -92,6 +92,15 @@ def test_world_one_robot_sharded_block_carries_the_audit_fields():
                                                     "link": "same device"}]
             pred[exchange] = roof["link"]["predicted_ms_per_step"]
     assert pred["spheres"] / pred["joints"] >= 2.5            # the link model's prediction, BASELINE config 4
+    # ... and the one multi-rank measurement a single GPU can make: three ranks x one robot inside the bench process
+    one = r["robot_sharded"]["one_die_group"]
+    assert "error" not in one, one
+    assert one["scenarios"] == 2016 and one["fused_kernel_ms_same_scenarios"] > 0
+    for exchange, scalars in (("joints", 21), ("spheres", 54)):
+        leg = one[exchange]
+        assert leg["parity_vs_fused_kernel"]["ok"] and leg["ms_device_slowest_rank"] > 0, leg
+        assert leg["bytes_per_rank_pair_per_step"] == scalars * 2016 * 8
+        assert (leg["comm_rank0"]["world"], leg["comm_rank0"]["robot_count"], leg["comm_rank0"]["peer_buffers_mapped"]) == (3, 1, 2)
 
 
 def test_bare_launch_spawns_its_own_ranks():
