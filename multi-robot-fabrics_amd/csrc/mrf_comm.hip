@@ -969,6 +969,9 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
           const int k = std::atoi(mg);
           if (k >= 1 && (unsigned)k < resident) resident = (unsigned)k;
         }
+        // a group of one waits for nobody: no residency requirement, one workgroup per block as the fused kernel launches
+        // them (the dispatcher balances the tail; the block loop then runs once)
+        if (c->world == 1) resident = nblk;
         dim3 block(64), grid(nblk < resident ? nblk : resident);
         if (std::getenv("MRF_PEER_DEBUG")) {
           timespec ts;
