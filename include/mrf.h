@@ -333,6 +333,10 @@ int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all);
  * each other on the device) before any of them is synchronised.  Ranks that share a device share its workgroup slots.
  * Used by the single-process tests of the multi-rank kernels at production grid sizes and by tools/shard_local.py. */
 int mrf_comm_peer_local_base(const mrf_handle* h, void** base_out);
+/* *concurrent_out = 1 when a kernel on stream_b runs while a kernel on stream_a is still running (HIP maps streams onto a
+ * few hardware queues; two streams that share one run their kernels one after the other, and persistent kernels that wait
+ * for each other would then wait for ever -- until the bounded wait gives up).  Takes up to 20 ms when they do not. */
+int mrf_streams_concurrent(int32_t device, void* stream_a, void* stream_b, int32_t* concurrent_out);
 int mrf_comm_peer_connect_local(mrf_handle* h, void* const* bases_all);
 int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot_count);
 /* What the communicator of this handle is, for logs that must prove what ran (bench.py's robot_sharded block): out[i],

@@ -87,7 +87,7 @@ EXPORTS = [
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
     "mrf_comm_info", "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
     "mrf_step_predict_joints", "mrf_step_action_joints", "mrf_exchange_scalars", "mrf_comm_peer_info", "mrf_device_topology",
-    "mrf_comm_peer_local_base", "mrf_comm_peer_connect_local",
+    "mrf_comm_peer_local_base", "mrf_comm_peer_connect_local", "mrf_streams_concurrent",
 ]
 
 ROLLOUT_JOINTSPACE, ROLLOUT_CARTESIAN = 0, 1
@@ -268,6 +268,8 @@ def load_library(path=None):
         lib.mrf_comm_peer_local_base.restype = C.c_int
         lib.mrf_comm_peer_connect_local.argtypes = [vp, C.POINTER(vp)]
         lib.mrf_comm_peer_connect_local.restype = C.c_int
+        lib.mrf_streams_concurrent.argtypes = [i32, vp, vp, C.POINTER(i32)]
+        lib.mrf_streams_concurrent.restype = C.c_int
     lib.mrf_rollout_sharded.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     lib.mrf_rollout_sharded.restype = C.c_int
     lib.mrf_comm_status.argtypes = [vp]

@@ -395,6 +395,21 @@ __global__ __launch_bounds__(64) void k_peer_roll_call(unsigned* __restrict__ co
   }
 }
 
+// Do kernels on two streams of one process really run side by side?  (HIP maps streams onto a few hardware queues; two
+// streams on one queue run their kernels one after the other.)  k_pair_wait spins, bounded, on a word that k_pair_set, queued
+// AFTER it on the other stream, writes.
+__global__ void k_pair_wait(unsigned* __restrict__ flag, unsigned* __restrict__ seen, long long timeout_ticks) {
+  const long long t0 = wall_clock64();
+  unsigned v = 0;
+  do {
+    v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v) break;
+    __builtin_amdgcn_s_sleep(8);
+  } while (wall_clock64() - t0 < timeout_ticks);
+  *seen = v;
+}
+__global__ void k_pair_set(unsigned* __restrict__ flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // After k_rollout_peer (same stream): one thread latches the error word, then every row is committed from that latch --
 // all rows advance, or (a timed-out exchange: some step folded stale payload) none does and the velocity signal is NaN,
 // so that a caller that forgets mrf_comm_status cannot take the result for a rollout.
@@ -778,6 +793,27 @@ int mrf_comm_peer_connect(mrf_handle* h, const void* ipc_handles_all) {
     if (c->grid_cap == 0) return fail(h, MRF_E_DEVICE, "peer transport: the residency roll call could not place a single workgroup");
   }
   c->connected = true;
+  return MRF_OK;
+}
+
+int mrf_streams_concurrent(int32_t device, void* stream_a, void* stream_b, int32_t* concurrent_out) {
+  if (!concurrent_out || stream_a == stream_b) return MRF_E_ARG;
+  mrf_host::DeviceGuard guard(device);
+  unsigned* d = nullptr;
+  if (hipMalloc((void**)&d, 8) != hipSuccess || hipMemset(d, 0, 8) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    if (d) (void)hipFree(d);
+    return MRF_E_DEVICE;
+  }
+  int rate_khz = 100000;
+  (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device);
+  hipLaunchKernelGGL(mrf::k_pair_wait, dim3(1), dim3(1), 0, (hipStream_t)stream_a, d, d + 1, (long long)rate_khz * 20);  // 20 ms
+  hipLaunchKernelGGL(mrf::k_pair_set, dim3(1), dim3(1), 0, (hipStream_t)stream_b, d);
+  unsigned r[2] = {0, 0};
+  const bool ok = hipStreamSynchronize((hipStream_t)stream_a) == hipSuccess && hipStreamSynchronize((hipStream_t)stream_b) == hipSuccess &&
+                  hipMemcpy(r, d, 8, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return MRF_E_DEVICE;
+  *concurrent_out = r[1] != 0u;
   return MRF_OK;
 }
 

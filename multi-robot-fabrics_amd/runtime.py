@@ -33,6 +33,16 @@ def device_topology(cap=16):
             "link_type": grid(lt, lambda v: abi.LINK_TYPE_NAMES.get(int(v), str(int(v)))), "hops": grid(hp)}
 
 
+def streams_concurrent(device_index, stream_a, stream_b):
+    """True when kernels on the two torch streams really run side by side (mrf_streams_concurrent)."""
+    lib = abi.load_library()
+    out = C.c_int32(0)
+    rc = lib.mrf_streams_concurrent(int(device_index), C.c_void_p(stream_a.cuda_stream), C.c_void_p(stream_b.cuda_stream), C.byref(out))
+    if rc != 0:
+        raise MrfError(f"mrf_streams_concurrent: {abi.STATUS_TEXT.get(rc, rc)}")
+    return bool(out.value)
+
+
 class FabricHandle:
     """Owns an `mrf_handle` (immutable constants on the device).  Not thread-safe, like the C handle."""
 

@@ -450,7 +450,22 @@ class InProcessGroup:
         self.parts = robot_partition(self.N, G)
         devices = list(devices) if devices is not None else [0] * G
         self.handles = [FabricHandle(cfg, devices[g]) for g in range(G)]
-        self.streams = [torch.cuda.Stream(device=devices[g]) for g in range(G)]
+        # one stream per rank whose kernels REALLY run beside those of the ranks already placed on the same device: HIP maps
+        # streams onto a few hardware queues, and two ranks on one queue would wait for each other until the bounded wait
+        # gives up (seen once in ~10 runs of the test suite before this check)
+        from .runtime import streams_concurrent
+        self.streams = []
+        for g in range(G):
+            for attempt in range(24):
+                st = torch.cuda.Stream(device=devices[g])
+                mates = [s for s, d in zip(self.streams, devices) if d == devices[g]]
+                if all(st.cuda_stream != m.cuda_stream and streams_concurrent(devices[g], m, st) and streams_concurrent(devices[g], st, m)
+                       for m in mates):
+                    self.streams.append(st)
+                    break
+            else:
+                raise RuntimeError(f"no stream found whose kernels run beside those of the {len(mates)} ranks already on device "
+                                   f"{devices[g]} (hardware queues exhausted: GPU_MAX_HW_QUEUES)")
         for g, h in enumerate(self.handles):
             h.comm_peer_open(g, G, max_scenarios)
         bases = [h.comm_peer_local_base() for h in self.handles]
