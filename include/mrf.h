@@ -348,8 +348,10 @@ int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot
  *   12 peers whose mapped buffer lies on a device this one reaches in ONE hop (hipExtGetLinkTypeAndHopCount; -1: not
  *      a connected PEER communicator)
  *   13 workgroups of the persistent PEER kernel's footprint found CO-RESIDENT on this device by the roll call of
- *      mrf_comm_peer_connect -- the cap of that kernel's grid (0: not measured: a group of one, or ranks sharing a device) */
-#define MRF_COMM_INFO_N 14
+ *      mrf_comm_peer_connect -- the cap of that kernel's grid (0: not measured: a group of one, or ranks sharing a device)
+ *   14 the last mrf_rollout_sharded of the PEER transport walked its blocks in PAIRS (k_rollout_peer_paired: joint payload,
+ *      more blocks than workgroup slots; the exchange of one block runs under the step of the other) */
+#define MRF_COMM_INFO_N 15
 int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n);
 int32_t mrf_comm_transport(const mrf_handle* h);
 /* Where the exchange buffers of a connected PEER communicator really are, per rank g of the group: out[g*MRF_PEER_INFO_N + i]

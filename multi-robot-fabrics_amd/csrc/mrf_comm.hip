@@ -80,9 +80,11 @@ __device__ __forceinline__ float quiet_nan<float>() { return __builtin_bit_cast(
 // The wave's payload stores are performed, then the per-workgroup flag goes up on every rank (own included: unused).
 // Once the group is in error (this rank timed out, or a peer did and said so in this rank's error word) no further flag
 // goes up: the payload behind it may have been computed from stale data, and the peers must time out -- or see the error
-// -- rather than fold it.
+// -- rather than fold it.  `broken_seen` is the wave's memory of that: read from the error word once per block, set by the
+// first wait that ends without its flags (peer_wait_flags) -- a flag therefore only ever stands for a payload computed from
+// data that arrived, and the publish needs no uncached read of the error word (1.5 us of every step, measured round 6).
 __device__ __forceinline__ void peer_raise_flags(const PeerView& V, int gen, int blk, unsigned long long seq, const int* err,
-                                                 int etag, int lane) {
+                                                 int etag, int lane, [[maybe_unused]] bool broken_seen) {
 #ifdef MRF_PEER_HEAVY_FENCE  // round 5's form: a system-scope fence (L2 write-back) and a system-scope release on top
   __threadfence_system();
   __syncthreads();
@@ -96,15 +98,15 @@ __device__ __forceinline__ void peer_raise_flags(const PeerView& V, int gen, int
   // system-scope store.  Measured with three ranks in one process (tools/shard_local.py, round 6): see DESIGN.md section 6.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
-  const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
-  if (lane < V.G && lane != V.grank && !broken)
+  if (lane < V.G && lane != V.grank && !broken_seen)
     __hip_atomic_store(peer_flag(V, lane, gen, V.grank, blk), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
 
 // wait for the same workgroup of every other rank (bounded: a missing peer must not hang the GPU)
 __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int blk, unsigned long long seq, const int* err,
-                                                int etag, int lane) {
+                                                int etag, int lane, bool& broken_seen) {
+  bool gave_up = false;
   if (lane < V.G && lane != V.grank) {
     const unsigned long long* f = peer_flag(V, V.grank, gen, lane, blk);
     const long long t0 = wall_clock64();
@@ -124,8 +126,12 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
       for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles
       if (naps < 8) naps *= 2;
 #endif
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) {
+        gave_up = true;
+        break;
+      }
       if (wall_clock64() - t0 > V.timeout_ticks) {
+        gave_up = true;
         // post-mortem of the FIRST wait that ran out on this rank (mrf_comm_status prints it under MRF_PEER_DEBUG): which
         // block, which peer, which sequence number was expected and what the flag held
         {
@@ -158,6 +164,7 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
 #endif
     }
   }
+  if (__any(gave_up)) broken_seen = true;
   __syncthreads();
 #ifdef MRF_PEER_HEAVY_FENCE
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every lane reads the peers' payload after the flags
@@ -165,6 +172,25 @@ __device__ __forceinline__ void peer_wait_flags(const PeerView& V, int gen, int 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... by system-scope loads, which no cache of this device answers
 #endif
 }
+
+// Development aid (-DMRF_PEER_TIMING, tools/peer_timing.py): where a wave of the persistent kernels spends its time -- publish
+// (payload stores, release, flags), the wait for the peers' flags, the remote fold (payload loads, re-walked chains), the
+// whole block -- in wall_clock64 ticks, summed over the waves of a launch into the words behind the post-mortem area.
+#ifdef MRF_PEER_TIMING
+#define MRF_TM(var, ...)                  \
+  {                                       \
+    const long long tm0_ = wall_clock64(); \
+    __VA_ARGS__;                          \
+    var += wall_clock64() - tm0_;         \
+  }
+#define MRF_TM_BEGIN() const long long tmb_ = wall_clock64()
+#define MRF_TM_END(var) var += wall_clock64() - tmb_
+#else
+#define MRF_TM(var, ...) \
+  { __VA_ARGS__; }
+#define MRF_TM_BEGIN()
+#define MRF_TM_END(var)
+#endif
 
 // q_in / qd_in are only read; the advanced state and the velocity signal go to the STAGING arrays q_st / qd_st / avg_st
 // (owned by the communicator) and are committed to the caller's arrays by k_peer_commit after the whole grid has
@@ -188,6 +214,8 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   const int lane = threadIdx.x;
   const int nblk = (int)((n_scen + spw - 1) / spw);
   if constexpr (LO) stage_sphere_radii(cfg, xch, lane);  // visible after the first barrier; never overwritten
+  [[maybe_unused]] long long tm_pub = 0, tm_wait = 0, tm_remote = 0, tm_all = 0, tm_stage = 0;
+  [[maybe_unused]] const long long tm_start = wall_clock64();
 #ifdef MRF_PEER_HEARTBEAT
   if (lane == 0) {  // development aid: how many workgroups of which launch have started (read by mrf_comm_status's post-mortem)
     int* dbg = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
@@ -225,6 +253,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   const int etag = (int)(seq0 >> 40) + 1;
   // without collision leaves (the grasp planner) nobody reads anybody's spheres: no payload, no flags, on every rank
   const bool exchanging = REMOTE && V.G > 1 && cfg.n_ego > 0;
+  bool broken_seen = exchanging && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
 
   PandaState<T> R;
   load_state(rows, row, q_in, qd_in, R);
@@ -270,6 +299,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
       // ---- publish: the joint state of step k goes out BEFORE the own chain walk, so that the flag round trip runs
       // under the walk and the local fold (FPJ:211-225 across GPUs; the receivers re-walk this chain)
       if (exchanging) {
+        MRF_TM_BEGIN();
         if (active) {
           for (int g = 0; g < V.G; ++g) {
             if (g == V.grank) continue;
@@ -282,7 +312,8 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
             }
           }
         }
-        peer_raise_flags(V, gen, blk, seq, err, etag, lane);
+        peer_raise_flags(V, gen, blk, seq, err, etag, lane, broken_seen);
+        MRF_TM_END(tm_pub);
       }
     }
     const T* xloc = peer_x<T>(V, V.grank, gen, N);
@@ -330,22 +361,23 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
                 }
               }
             }
-            peer_raise_flags(V, gen, blk, seq, err, etag, lane);
+            peer_raise_flags(V, gen, blk, seq, err, etag, lane, broken_seen);
           }
         },
         [&]() {
-          if (exchanging) peer_wait_flags(V, gen, blk, seq, err, etag, lane);
+          if (exchanging) MRF_TM(tm_wait, peer_wait_flags(V, gen, blk, seq, err, etag, lane, broken_seen))
         },
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           if constexpr (XK == XK_JOINTS) {
-            remote_obstacles_joints<typename LS::Collision, LO>(
+            MRF_TM(tm_remote, remote_obstacles_joints<typename LS::Collision, LO>(
                 cfg, xch, lane, first, count, N,
-                [&](int jr, int c) { return xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * V.b_max + scen); }, E, acc);
+                [&](int jr, int c) { return xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * V.b_max + scen); }, E, acc,
+                &tm_stage))
           } else if constexpr (XK == XK_SPHERES) {
             const int SX = cfg.n_spheres - m01 - m45;
-            remote_obstacles_spheres<typename LS::Collision, LO>(
+            MRF_TM(tm_remote, remote_obstacles_spheres<typename LS::Collision, LO>(
                 cfg, first, count, N,
-                [&](int jr, int slot, int c) { return xload(xloc + ((size_t)(jr * SX + slot) * 9 + c) * V.b_max + scen); }, E, acc);
+                [&](int jr, int slot, int c) { return xload(xloc + ((size_t)(jr * SX + slot) * 9 + c) * V.b_max + scen); }, E, acc))
           }
         },
         qdd, act);
@@ -367,6 +399,243 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
   }
 #ifdef MRF_PEER_HEARTBEAT
   if (lane == 0) atomicAdd(reinterpret_cast<int*>(V.base[V.grank] + V.off_err) + 12, 1);  // workgroups that have left
+#endif
+#ifdef MRF_PEER_TIMING
+  if (lane == 0) {
+    unsigned long long* tm = reinterpret_cast<unsigned long long*>(V.base[V.grank] + V.off_err + 128);
+    tm_all = wall_clock64() - tm_start;
+    atomicAdd(tm + 0, (unsigned long long)tm_pub);
+    atomicAdd(tm + 1, (unsigned long long)tm_wait);
+    atomicAdd(tm + 2, (unsigned long long)tm_remote);
+    atomicAdd(tm + 3, (unsigned long long)tm_all);
+    atomicAdd(tm + 4, 1ull);
+    atomicAdd(tm + 5, (unsigned long long)tm_stage);
+  }
+#endif
+}
+
+// k_rollout_peer_paired (round 6; OPT-IN, MRF_PEER_PAIRED=1: a parity-green experiment that does not pay with all ranks on one
+// die -- see the host side and DESIGN.md section 6): the joint payload's kernel for batches of more than one block per
+// workgroup.  A workgroup works on the two ADJACENT blocks 2u and 2u + 1 in turns -- step k of the first, step k of the second, step k + 1 of the
+// first ... -- and publishes the joint state of step k + 1 at the END of step k (it is known as soon as the action is).  The round trip of a block's exchange -- the
+// write-through of the payload, the flag, the peers' polls, over xGMI between GPUs -- then runs under the whole step of the
+// OTHER block instead of stalling the only wave of the SIMD.  The state of the block that is not being worked on (q, cos q,
+// sin q, qdot, the velocity sum, the goal estimate: 32 scalars per lane) sits in `swap`, an L2-resident 16 KB per workgroup,
+// and is exchanged in place at each turn (the LDS is taken by the exchange tile: 37 of the 40 KB a wave has at four waves
+// per CU).  The pairing is by block index, not by grid size, and every rank runs the two blocks of a pair in the same
+// order, so the wait graph stays acyclic whatever the ranks' grid sizes: the lowest unfinished pair is current on every rank.
+constexpr int PEER_SWAP_SCALARS = 32;
+template <typename T, class LS, bool LO>
+__global__ __launch_bounds__(64) void k_rollout_peer_paired(const DevCfg<T>* __restrict__ cfgp, PeerView V, int64_t n_scen,
+                                                      const T* __restrict__ q_in, const T* __restrict__ qd_in,
+                                                      const T* __restrict__ prm, T* __restrict__ q_st,
+                                                      T* __restrict__ qd_st, T* __restrict__ avg_st, T* swap,
+                                                      unsigned long long seq0) {
+  __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
+  const DevCfg<T>& cfg = *cfgp;
+  const int N = cfg.n_robots;
+  const int first = V.first[V.grank], count = V.first[V.grank + 1] - first;
+  int cnt_max = 1;
+  for (int g = 0; g < V.G; ++g) cnt_max = max(cnt_max, V.first[g + 1] - V.first[g]);
+  const int spw = 64 / cnt_max;  // scenarios per block: the same on every rank, so block X is the same scenarios
+  const int lane = threadIdx.x;
+  const int nblk = (int)((n_scen + spw - 1) / spw);
+  if constexpr (LO) stage_sphere_radii(cfg, xch, lane);  // visible after the first barrier; never overwritten
+  [[maybe_unused]] long long tm_pub = 0, tm_wait = 0, tm_remote = 0, tm_all = 0, tm_stage = 0;
+  [[maybe_unused]] const long long tm_start = wall_clock64();
+#ifdef MRF_PEER_HEARTBEAT
+  if (lane == 0) {  // development aid: how many workgroups of which launch have started (read by mrf_comm_status's post-mortem)
+    int* dbg = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
+    const int tag = (int)(seq0 & 0x7fffffff);
+    if (atomicExch(dbg + 8, tag) != tag) {
+      atomicExch(dbg + 9, 0);
+      atomicExch(dbg + 12, 0);
+    }
+    atomicAdd(dbg + 9, 1);
+  }
+#endif
+  const int64_t rows = n_scen * count;
+  int* err = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
+  // The error word is tagged with the reset epoch (the high bits of every sequence number, mrf_comm_reset): "broken" means
+  // "holds THIS epoch's tag", so a kernel of the previous epoch that times out late -- after a peer's reset has already
+  // started the next epoch -- cannot break the new sequence with its store.
+  const int etag = (int)(seq0 >> 40) + 1;
+  // without collision leaves (the grasp planner) nobody reads anybody's spheres: no payload, no flags, on every rank
+  const bool exchanging = V.G > 1 && cfg.n_ego > 0;
+  const int H = cfg.horizon;
+  T* sw = swap + (size_t)blockIdx.x * PEER_SWAP_SCALARS * 64 + lane;
+  // The grid is capped at what is resident at once (host side); a workgroup then walks units blockIdx.x,
+  // blockIdx.x + gridDim.x, ... in increasing order (a unit: one block, or a pair of adjacent blocks).  Block X only ever
+  // waits for block X of the peers, every workgroup of every rank is resident and visits its units in increasing index
+  // order, so the wait graph has no cycle whatever the dispatch order or the grid size of the other ranks.
+  const int nunit = (nblk + 1) / 2;
+#pragma unroll 1
+  for (int unit = blockIdx.x; unit < nunit; unit += gridDim.x) {
+  const int nctx = 2 * unit + 1 < nblk ? 2 : 1;  // an odd block count leaves the last pair with one block
+  bool broken_seen = exchanging && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag;
+  // ---- the block being worked on: lane -> (scenario, owned robot)
+  int blk = 0, ls = 0, l = 0, me = first;
+  int64_t scen = 0, row = 0;
+  bool active = false;
+  auto map_block = [&](int b) __attribute__((always_inline)) {
+    blk = b;
+    ls = lane / count;
+    const int l0 = lane - ls * count;
+    scen = (int64_t)blk * spw + ls;
+    active = ls < spw && scen < n_scen;
+    if (!active) {  // idle lanes shadow the block's first row (no stores)
+      ls = 0;
+      scen = (int64_t)blk * spw;
+    }
+    l = active ? l0 : 0;
+    me = first + l;
+    row = scen * count + l;
+  };
+  PandaState<T> R;
+  T g0[3] = {T(0), T(0), T(0)};
+  T sumsq = T(0);
+  // system_step 'vel' (FPJ:77-80)
+  auto integrate = [&]() __attribute__((always_inline)) {
+    T dq[7];
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      dq[j] = cfg.dt * R.qd[j];
+      small = small && (m_abs(dq[j]) < T(0.125));
+      R.q[j] += dq[j];
+    }
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T sd, cd;
+        small_sincos(dq[j], sd, cd);
+        const T c = R.cq[j] * cd - R.sq[j] * sd;
+        const T s = R.sq[j] * cd + R.cq[j] * sd;
+        R.cq[j] = c;
+        R.sq[j] = s;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    }
+  };
+  // ---- publish: the joint state a step starts from goes out as soon as it is known -- before the own chain
+  // walk of that step (FPJ:211-225 across GPUs; the receivers re-walk this chain)
+  auto publish_joints = [&](unsigned long long seq) __attribute__((always_inline)) {
+    if (!exchanging) return;
+    const int gen = (int)(seq & 1ull);
+    MRF_TM_BEGIN();
+    if (active) {
+      for (int g = 0; g < V.G; ++g) {
+        if (g == V.grank) continue;
+        T* dst = peer_x<T>(V, g, gen, N) + ((size_t)me * MRF_JOINT_STATE_SCALARS) * V.b_max + scen;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          xstore(dst + (size_t)(3 * j + 0) * V.b_max, R.cq[j]);
+          xstore(dst + (size_t)(3 * j + 1) * V.b_max, R.sq[j]);
+          xstore(dst + (size_t)(3 * j + 2) * V.b_max, R.qd[j]);
+        }
+      }
+    }
+    peer_raise_flags(V, gen, blk, seq, err, etag, lane, broken_seen);
+    MRF_TM_END(tm_pub);
+  };
+  // the state of the block that is not being worked on <-> registers, in place (same lane, same address: in order)
+  auto swap_state = [&]() __attribute__((always_inline)) {
+    auto x = [&](int i, T& v) __attribute__((always_inline)) {
+      const T t = sw[i * 64];
+      sw[i * 64] = v;
+      v = t;
+    };
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      x(j, R.q[j]);
+      x(7 + j, R.qd[j]);
+      x(14 + j, R.cq[j]);
+      x(21 + j, R.sq[j]);
+    }
+    x(28, sumsq);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x(29 + c, g0[c]);
+  };
+  // ---- prologue of every block of the unit: start state, RF-CV goal estimate, the position update of step 0, its publish
+#pragma unroll 1
+  for (int w = 0; w < nctx; ++w) {
+    if (w == 1) swap_state();  // the first block's state goes to the swap area (what comes back is not used)
+    map_block(2 * unit + w);
+    load_state(rows, row, q_in, qd_in, R);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g0[c] = T(0);
+    if ((cfg.goal_mask >> me) & 1) {  // RF-CV goal estimate (EXC:355-357), as in k_rollout_panda
+      PandaKin<T> K0;
+      panda_walk_own<T>(cfg.mount[me], R.cq, R.sq, R.qd, K0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g0[c] = K0.p8[c] + cfg.goal_T * K0.v8[c];
+    }
+    sumsq = T(0);
+    integrate();
+    publish_joints(seq0);
+  }
+#pragma unroll 1
+  for (int it = 0; it < nctx * H; ++it) {
+    int k = it;
+    if (nctx == 2) {
+      k = it >> 1;
+      swap_state();
+      map_block(2 * unit + (it & 1));
+    }
+    const unsigned long long seq = seq0 + (unsigned long long)k;
+    const int gen = (int)(seq & 1ull);
+    const T* mount_own = cfg.mount[me];
+    PrmView<T> P{prm, rows, row, {g0[0], g0[1], g0[2]}, ((cfg.goal_mask >> me) & 1) != 0};
+    const T* xloc = peer_x<T>(V, V.grank, gen, N);
+    T qdd[7], act[7];
+    sharded_solve_row<LS, LO, true>(
+        cfg, xch, lane, ls, l, count, mount_own, R, P,
+        [&](const PandaKin<T>&) {},
+        [&]() {
+          if (exchanging) MRF_TM(tm_wait, peer_wait_flags(V, gen, blk, seq, err, etag, lane, broken_seen))
+        },
+        [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
+          MRF_TM(tm_remote, remote_obstacles_joints<typename LS::Collision, LO>(
+              cfg, xch, lane, first, count, N,
+              [&](int jr, int c) { return xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * V.b_max + scen); }, E, acc,
+              &tm_stage))
+        },
+        qdd, act);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      R.qd[j] = act[j];  // FPJ:233
+      sumsq += act[j] * act[j];
+    }
+    if (k + 1 < H) {
+      integrate();  // the position update of step k + 1 ...
+      publish_joints(seq + 1ull);  // ... and its joint state, on its way while the rest of the unit is worked on
+    } else if (active) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        q_st[j * rows + row] = R.q[j];
+        qd_st[j * rows + row] = R.qd[j];
+      }
+      avg_st[row] = sumsq / (T)(H * 7);  // FPJ:102-116
+    }
+  }
+  __syncthreads();  // xch is rewritten by the next unit of this workgroup
+  }
+#ifdef MRF_PEER_HEARTBEAT
+  if (lane == 0) atomicAdd(reinterpret_cast<int*>(V.base[V.grank] + V.off_err) + 12, 1);  // workgroups that have left
+#endif
+#ifdef MRF_PEER_TIMING
+  if (lane == 0) {
+    unsigned long long* tm = reinterpret_cast<unsigned long long*>(V.base[V.grank] + V.off_err + 128);
+    tm_all = wall_clock64() - tm_start;
+    atomicAdd(tm + 0, (unsigned long long)tm_pub);
+    atomicAdd(tm + 1, (unsigned long long)tm_wait);
+    atomicAdd(tm + 2, (unsigned long long)tm_remote);
+    atomicAdd(tm + 3, (unsigned long long)tm_all);
+    atomicAdd(tm + 4, 1ull);
+    atomicAdd(tm + 5, (unsigned long long)tm_stage);
+  }
 #endif
 }
 
@@ -541,6 +810,9 @@ struct Comm {
   int nblk_max = 0;
   size_t off_flags = 0, off_err = 0, off_x = 0, bytes = 0;
   void* stage = nullptr;  // peer kernel outputs before the commit: q [7][rows], qdot [7][rows], avg [rows], latch
+  void* swap = nullptr;   // paired blocks (joint payload): the resting block's state, [swap_wgs][32][64] scalars
+  unsigned swap_wgs = 0;
+  bool last_paired = false;  // the last rollout walked its blocks two at a time (MRF_PEER_DEBUG prints it)
   unsigned grid_cap = 0;   // co-resident workgroups measured by the roll call at connect (0: not measured -- a group of one,
                            // or ranks sharing a device in tests)
   unsigned long long epoch = 0;  // mrf_comm_reset count: the high bits of every sequence number
@@ -635,6 +907,7 @@ void mrf_host::comm_release(mrf_handle* h) {
     if (c->peer[g] && g != c->rank && !c->in_process) (void)hipIpcCloseMemHandle(c->peer[g]);
   if (c->local) (void)hipFree(c->local);
   if (c->stage) (void)hipFree(c->stage);
+  if (c->swap) (void)hipFree(c->swap);
   delete c;
   h->comm = nullptr;
 }
@@ -716,7 +989,7 @@ int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n) {
       c ? c->transport : MRF_TRANSPORT_NONE, c ? c->rank : 0, c ? c->world : 0, c ? c->first[c->rank] : 0,
       c ? c->first[c->rank + 1] - c->first[c->rank] : 0, c ? c->nccl_count : 0, c ? c->nccl_rank : -1,
       c ? c->nccl_device : -1, h->device, c && c->transport == MRF_TRANSPORT_PEER && c->connected ? c->world - 1 : 0,
-      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop, c ? (int32_t)c->grid_cap : 0};
+      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop, c ? (int32_t)c->grid_cap : 0, c && c->last_paired ? 1 : 0};
   for (int i = 0; i < n && i < MRF_COMM_INFO_N; ++i) out[i] = vals[i];
   return MRF_OK;
 }
@@ -757,6 +1030,18 @@ int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_s
     (void)hipFree(c->local);
     delete c;
     return fail(h, MRF_E_DEVICE, "staging buffer of the peer rollout");
+  }
+  if (world > 1 && c->xs == MRF_JOINT_STATE_SCALARS) {
+    // k_rollout_peer_paired: 16 KB (float64) per workgroup of the largest resident grid (one wave per SIMD)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    c->swap_wgs = (unsigned)cus * 4u;
+    if (hipMalloc(&c->swap, (size_t)c->swap_wgs * mrf::PEER_SWAP_SCALARS * 64 * scalar_bytes(h)) != hipSuccess) {
+      (void)hipFree(c->local);
+      (void)hipFree(c->stage);
+      delete c;
+      return fail(h, MRF_E_DEVICE, "swap area of the peer rollout");
+    }
   }
   std::memcpy(ipc_handle_out, &mh, sizeof(mh));
   c->peer[rank] = c->local;
@@ -966,41 +1251,55 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     const bool lo = is_link_origin_table(h->cfg);
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    // several ranks on ONE device share its workgroup slots (test layouts):
+    //   MRF_PEER_DEVICE_SHARE = k processes whose peer kernels must be resident together: three quarters of a k-th each.
+    //     What round 6 found about this layout at large batches -- a small kernel in FRONT of a rank's peer kernel is
+    //     starved while the other ranks' peer kernels wait on the same device -- is handled where the rollouts are issued
+    //     (sharded.py, DESIGN.md section 6 "Residency"), not by the size of the share;
+    //   the ranks of an in-process group that live on this device run their persistent kernels side by side: a share each
+    //     (ranks on other devices of the process do not count).
+    unsigned here = 0;
+    if (c->in_process && c->world > 1) {
+      for (int g = 0; g < c->world; ++g) {
+        hipPointerAttribute_t at;
+        std::memset(&at, 0, sizeof(at));
+        if (hipPointerGetAttributes(&at, c->peer[g]) == hipSuccess && at.device == h->device) here += 1;
+      }
+      (void)hipGetLastError();
+    }
+    const char* sh = std::getenv("MRF_PEER_DEVICE_SHARE");
+    const int share_k = sh ? std::atoi(sh) : 0;
+    auto device_share = [&](unsigned slots) {
+      if (share_k > 1) slots = slots / (unsigned)share_k * 3u / 4u;
+      if (here > 1) slots = slots / here;
+      return slots < 1u ? 1u : slots;
+    };
+    // Paired blocks (k_rollout_peer_paired), OPT-IN (MRF_PEER_PAIRED=1, the same on every rank): where a workgroup has more
+    // than one block to walk -- more blocks than this rank's share of one wave per SIMD -- it walks them two at a time and
+    // the flag round trip of one runs under the step of the other.  Not the default: with all ranks on one die it measures
+    // 5-13 % SLOWER than a block at a time (DESIGN.md section 6 "Where a sharded step's time goes": what a step loses to
+    // the exchange is the wave's own store drain and poll round trips, which a second block does not hide), and the layout
+    // it is meant for -- flags crossing xGMI -- cannot be measured on a one-GPU box.  EVERY rank of a group must come to the
+    // same answer (a pair is worked on in turns, a single block is not), so it depends on the batch, the device model and
+    // the share only -- not on the measured residency or the occupancy of the kernel; MRF_PEER_PAIRED_MIN_BLOCKS moves the
+    // threshold (tests: 2).  Ranks that disagree time out with the exchange error, they do not hang.
+    unsigned paired_min = device_share((unsigned)cus * 4u) + 1u;
+    if (const char* pm = std::getenv("MRF_PEER_PAIRED_MIN_BLOCKS"))
+      if (std::atoi(pm) >= 2) paired_min = (unsigned)std::atoi(pm);
+    const char* pe = std::getenv("MRF_PEER_PAIRED");
+    const bool paired = c->world > 1 && c->xs == MRF_JOINT_STATE_SCALARS && c->swap && nblk >= paired_min && pe && std::atoi(pe) == 1;
+    c->last_paired = paired;
     return dispatch(h, [&](auto t, auto cl) {
       using T = decltype(t);
       using LS = decltype(cl);
-      auto go = [&](auto kernel) {
+      auto go = [&](auto kernel, auto... swap_area) {  // swap_area: k_rollout_peer_paired's extra argument
         // every workgroup of the launch must be resident: a block waits for the same block of the peers, and a
         // workgroup that has not started cannot publish (HIP promises no dispatch order)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         unsigned resident = (unsigned)per_cu * (unsigned)cus;
         if (c->grid_cap && c->grid_cap < resident) resident = c->grid_cap;  // what the roll call at connect found co-resident
-        // several ranks on ONE device (the single-GPU test hook) share its workgroup slots: MRF_PEER_DEVICE_SHARE = number
-        // of processes whose peer kernels must be resident together
-        if (const char* sh = std::getenv("MRF_PEER_DEVICE_SHARE")) {
-          // k > 1: a TEST layout (several processes on one device): three quarters of the share.  What round 6 found about
-          // this layout at large batches -- a small kernel in FRONT of a rank's peer kernel is starved while the other
-          // ranks' peer kernels wait on the same device -- is handled where the rollouts are issued (sharded.py, DESIGN.md
-          // section 6 "Residency"), not by the size of the share.
-          const int k = std::atoi(sh);
-          if (k > 1) {
-            resident = resident / (unsigned)k * 3u / 4u;
-            if (resident < 1u) resident = 1u;
-          }
-        }
-        if (c->in_process && c->world > 1) {
-          // ranks of an in-process group that share this device run their persistent kernels side by side: each takes its
-          // share of the slots (ranks on other devices of the process do not count)
-          unsigned here = 0;
-          for (int g = 0; g < c->world; ++g) {
-            hipPointerAttribute_t at;
-            std::memset(&at, 0, sizeof(at));
-            if (hipPointerGetAttributes(&at, c->peer[g]) == hipSuccess && at.device == h->device) here += 1;
-          }
-          (void)hipGetLastError();
-          if (here > 1) resident = resident / here ? resident / here : 1u;
-        }
+        resident = device_share(resident);
         if (const char* mg = std::getenv("MRF_PEER_MAX_GRID")) {  // test hook: several blocks per workgroup at small batches
           const int k = std::atoi(mg);
           if (k >= 1 && (unsigned)k < resident) resident = (unsigned)k;
@@ -1008,12 +1307,15 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         // a group of one waits for nobody: no residency requirement, one workgroup per block as the fused kernel launches
         // them (the dispatcher balances the tail; the block loop then runs once)
         if (c->world == 1) resident = nblk;
-        dim3 block(64), grid(nblk < resident ? nblk : resident);
+        if (paired && c->swap_wgs < resident) resident = c->swap_wgs;  // one slot of the swap area per workgroup
+        const unsigned nunit = paired ? (nblk + 1u) / 2u : nblk;
+        dim3 block(64), grid(nunit < resident ? nunit : resident);
         if (std::getenv("MRF_PEER_DEBUG")) {
           timespec ts;
           clock_gettime(CLOCK_REALTIME, &ts);
-          std::fprintf(stderr, "[mrf peer %ld.%03ld] rank %d/%d: occupancy %d per CU x %d CUs -> resident %u, blocks %u, grid %u, seq0 %llu\n",
-                       (long)(ts.tv_sec % 1000), ts.tv_nsec / 1000000, c->rank, c->world, per_cu, cus, resident, nblk, grid.x,
+          std::fprintf(stderr, "[mrf peer %ld.%03ld] rank %d/%d: occupancy %d per CU x %d CUs -> resident %u, blocks %u%s, grid %u, seq0 %llu\n",
+                       (long)(ts.tv_sec % 1000), ts.tv_nsec / 1000000, c->rank, c->world, per_cu, cus, resident, nblk,
+                       paired ? " in pairs" : "", grid.x,
                        (unsigned long long)(seq0 & 0x7fffffff));
         }
         T* q_st = (T*)c->stage;
@@ -1021,7 +1323,7 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
         T* avg_st = qd_st + 7 * rows;
         int* latch = (int*)((unsigned char*)c->stage + (((size_t)15 * c->b_max * count * sizeof(T)) & ~(size_t)15) + 16);
         if (int rc = launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, V, n_scen, (const T*)q_io,
-                            (const T*)qdot_io, (const T*)params, q_st, qd_st, avg_st, seq0))
+                            (const T*)qdot_io, (const T*)params, q_st, qd_st, avg_st, swap_area..., seq0))
           return rc;
         if (int rc = launch(h, mrf::k_peer_latch, dim3(1), dim3(1), st, (const int*)(c->local + c->off_err), latch, c->world,
                             (int)(seq0 >> 40) + 1))
@@ -1038,6 +1340,8 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
       };
       // what the robots of other ranks send: nothing (a group of one: the fused kernel's step), joint states, spheres
       if (c->world == 1) return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_NONE>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_NONE>);
+      if (paired)
+        return lo ? go(mrf::k_rollout_peer_paired<T, LS, true>, (T*)c->swap) : go(mrf::k_rollout_peer_paired<T, LS, false>, (T*)c->swap);
       if (c->xs == MRF_JOINT_STATE_SCALARS)
         return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_JOINTS>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_JOINTS>);
       return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_SPHERES>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_SPHERES>);
@@ -1079,6 +1383,18 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     return launch(h, mrf::k_avg_from_sumsq<T>, grid, block, st, rows, (const T*)c->sumsq, (T)(1.0 / (H * 7)), (T*)avg_vel_out);
   });
 }
+
+#ifdef MRF_PEER_TIMING
+// development builds only: {publish, wait, remote fold, whole kernel} ticks summed over waves, waves counted, the payload
+// loads + staging part of the remote fold; then zeroed
+extern "C" int mrf_debug_peer_timing(mrf_handle* h, unsigned long long* out6) {
+  Comm* c = h ? (Comm*)h->comm : nullptr;
+  if (!c || !c->local || !out6) return MRF_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return MRF_E_DEVICE;
+  if (hipMemcpy(out6, c->local + c->off_err + 128, 48, hipMemcpyDeviceToHost) != hipSuccess) return MRF_E_DEVICE;
+  return hipMemset(c->local + c->off_err + 128, 0, 48) == hipSuccess ? MRF_OK : MRF_E_DEVICE;
+}
+#endif
 
 int mrf_comm_status(mrf_handle* h) {
   MRF_CHECK_READY(h);

@@ -32,6 +32,30 @@ struct RemoteStage {
   static constexpr int kOffset = LO ? 0 : GEN_XCH;
 };
 
+// emit_link hook of the UNROLLED chain walk (panda_walk_own) for the reference's link-origin table: the sphere of link L sits
+// at that link's origin and goes to this lane's column of the [72][64] tile the moment the walk has completed the link
+// (coincident origins once, as publish_link_spheres lays them out).  Folding inside the hook instead -- eight inlined leaf
+// evaluations along the unrolled walk -- was tried first: 1.5 KB of scratch per lane, 2.3x slower than the rolled walk.
+template <typename T>
+struct TileOriginEmit {
+  T* __restrict__ col;  // tile + lane
+  bool dyn;
+  T jsign;
+  int m01, m45;
+  __device__ __forceinline__ void operator()(int link, const T*, const T*, const T*, const T* o, const T*, const T*, const T* vo,
+                                             const T* ao) const {
+    const int s = link - 1;
+    if ((s == 1 && m01) || (s == 5 && m45)) return;
+    T* d9 = col + lo_slot(s, m01, m45) * 9 * 64;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      d9[c * 64] = o[c];
+      d9[(3 + c) * 64] = dyn ? vo[c] : T(0);          // FPJ:215-217
+      d9[(6 + c) * 64] = dyn ? jsign * ao[c] : T(0);  // FPJ:97-99 + UT:28
+    }
+  }
+};
+
 // Fold the spheres of every robot of another rank, re-derived from its exchanged joint state.  load(jr, c) returns scalar
 // c (0..20: cos, sin, qdot of joint c/3) of robot jr for THIS lane's scenario; all 21 loads of a robot are issued before
 // the first is used (one memory round trip per robot), then go to the LDS rows the rolled walk reads by joint index (a
@@ -39,16 +63,58 @@ struct RemoteStage {
 template <class CL, bool LO, typename T, class Load>
 __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T* __restrict__ xch, int lane, int first,
                                                         int count, int N, Load load, const EgoPts<T, NG>& E,
-                                                        EgoAcc<T, NG>& acc) {
-  constexpr int RCH = RemoteStage<LO>::kRobots;
-  T* stage = xch + RemoteStage<LO>::kOffset;
+                                                        EgoAcc<T, NG>& acc, [[maybe_unused]] long long* tm_stage = nullptr) {
   const int nrem = N - count;
   const bool dyn = cfg.dynamic != 0;
   const int m01 = LO ? cfg.lo_merge01 : 0, m45 = LO ? cfg.lo_merge45 : 0;
+#ifndef MRF_REMOTE_WALK_ROLLED
+  if constexpr (LO) {
+    // Link-origin table: the remote chain is walked by the UNROLLED walk straight from the 21 loaded scalars (registers: no
+    // joint-state stage, no walk loop whose every multiply-add waits for the one before in the only wave of the SIMD); its
+    // spheres go to this lane's OWN column of the tile and are folded from there by the loop the local fold uses.  The
+    // column is lane-private: one barrier frees the tile after the local fold, none between the remote robots.  Measured with three ranks on one die
+    // (tools/peer_timing.py, round 6): the rolled form's two walks cost 7 us of a 39 us step.
+    (void)tm_stage;
+    T* col = xch + lane;
+    const int SX = 8 - m01 - m45;
+    __syncthreads();  // the tile is free: the local fold has finished in every lane
+#pragma unroll 1
+    for (int d = 0; d < nrem; ++d) {
+      const int jr = remote_robot(d, first, count);
+      {
+        T cq[7], sq[7], qd[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          cq[j] = load(jr, 3 * j + 0);
+          sq[j] = load(jr, 3 * j + 1);
+          qd[j] = load(jr, 3 * j + 2);
+        }
+        PandaKin<T> K;  // outputs nobody reads: only the hook's stores survive
+        panda_walk_own<T, 7>(cfg.mount[jr], cq, sq, qd, K, TileOriginEmit<T>{col, dyn, cfg.jsign, m01, m45});
+      }
+      pipelined_pairs<T, 9>(
+          SX,
+          [&](int m, T (&sp)[9]) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sp[c] = col[(m * 9 + c) * 64];
+          },
+          [&](int m, T (&sp)[9]) {
+            const int sph = lo_sphere(m, m01, m45);
+            accumulate_obstacle<CL>(cfg, E, sp, sp + 3, sp + 6, cfg.sphere_r[sph], false, acc, T(lo_count(m, m01, m45)));
+          });
+    }
+    return;
+  }
+#endif
+  constexpr int RCH = RemoteStage<LO>::kRobots;
+  T* stage = xch + RemoteStage<LO>::kOffset;
 #pragma unroll 1
   for (int d0 = 0; d0 < nrem; d0 += RCH) {
     const int nch = nrem - d0 < RCH ? nrem - d0 : RCH;
     __syncthreads();  // the rows are free: the local fold / the previous chunk's walks have finished in every lane
+#ifdef MRF_PEER_TIMING
+    const long long tms_ = wall_clock64();
+#endif
 #pragma unroll 1
     for (int dd = 0; dd < nch; ++dd) {
       const int jr = remote_robot(d0 + dd, first, count);
@@ -59,6 +125,9 @@ __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T*
       for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) stage[(dd * MRF_JOINT_STATE_SCALARS + c) * 64 + lane] = v[c];
     }
     __syncthreads();
+#ifdef MRF_PEER_TIMING
+    if (tm_stage) *tm_stage += wall_clock64() - tms_;
+#endif
 #pragma unroll 1
     for (int dd = 0; dd < nch; ++dd) {
       const int jr = remote_robot(d0 + dd, first, count);

@@ -84,8 +84,9 @@ def test_comm_argument_errors():
     assert h.comm_partition() == (0, 2)
 
 
-def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port, roll_call=False):
+def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port, roll_call=False, extra_env=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="8000", MRF_PEER_DEVICE_SHARE=str(world))
+    env.update(extra_env or {})
     if roll_call:       # the residency roll call of mrf_comm_peer_connect runs although the ranks share the device
         env["MRF_PEER_ROLL_CALL"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
@@ -128,6 +129,25 @@ def test_three_and_four_processes_one_gpu_peer_exchange(world, n_robots, horizon
     for r in ranks:
         assert r["err"] < 1e-9, ranks
         assert r["scalars"] == (21 if exchange == "joints" else 9 * {"lo": 6, "offsets": 16, "offsets20": 20}[table])
+
+
+@pytest.mark.parametrize("world,n_robots,horizon,n_scen,table,dtype,max_grid", [
+    (2, 2, 6, 300, "lo", "f64", 2),           # 5 blocks: two pairs and a last unit of ONE block, on two workgroups
+    (3, 3, 5, 200, "lo", "f64", 1),           # one robot per rank, two remote chains; one workgroup walks both pairs
+    (2, 3, 4, 100, "offsets", "f64", 2),      # 2 + 1 robots: local exchange on chip AND a remote chain, generic table
+    (4, 8, 3, 70, "offsets20", "f64", 2),     # BASELINE config 5's table on 4 ranks
+    (2, 2, 5, 260, "lo", "f32", 3),
+])
+def test_paired_blocks_processes_one_gpu(world, n_robots, horizon, n_scen, table, dtype, max_grid):
+    """k_rollout_peer_paired (round 6): a workgroup works on two adjacent blocks in turns and publishes the joint state of step
+    k + 1 at the end of step k, so that one block's exchange runs under the other block's step.  Opt-in (MRF_PEER_PAIRED=1),
+    here at test sizes (MRF_PEER_PAIRED_MIN_BLOCKS=2, a grid of one to three workgroups); separate processes, IPC-mapped
+    buffers."""
+    ranks = _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, "joints", 29555,
+                                  extra_env={"MRF_PEER_PAIRED": "1", "MRF_PEER_PAIRED_MIN_BLOCKS": "2", "MRF_PEER_MAX_GRID": str(max_grid)})
+    for r in ranks:
+        assert r["paired"] == 1, ranks
+        assert r["err"] < (1e-9 if dtype == "f64" else 2e-3), ranks
 
 
 def test_plain_c_consumer_two_processes_one_gpu():
@@ -250,4 +270,37 @@ def test_in_process_group_at_production_grid_sizes(n_robots, G, n_scen, horizon,
             assert rel(avg, want[r]) < 1e-9 and rel(states[g][0], tq[-1][:, r]) < 1e-9 and rel(states[g][1], tqd[-1][:, r]) < 1e-9
     info = grp.handles[0].comm_info()
     assert info["world"] == G and info["peer_buffers_mapped"] == G - 1 and info["exchange"] == exchange
+    grp.close()
+
+
+def test_in_process_group_paired_blocks_reproduce_single_blocks(monkeypatch):
+    """MRF_PEER_PAIRED=1 above one block per workgroup slot: the joint payload's rollout walks its blocks in pairs
+    (k_rollout_peer_paired) at production grid sizes, reproduces the block-at-a-time kernel to rounding (two instantiations:
+    the compiler contracts their multiply-adds differently) and the fused kernel to the parity tolerance; switching back and
+    forth between the two on one communicator keeps the flag sequence intact."""
+    from multi_robot_fabrics_amd.sharded import InProcessGroup
+    n_robots, G, n_scen, horizon = 3, 3, 43008 + 64, 6           # 673 blocks per rank (odd: the last unit is one block)
+    cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+    cfg.goal_estimate_mask = 0b110
+    batch = scenarios.tiled_batch(cfg, n_scen, seed=9)
+    ref = FabricHandle(cfg, 0)
+    want, tq, tqd = ref.rollout(*(ref.tensor(batch[k]) for k in ("q", "qdot", "params")), want_traj=True)
+    grp = InProcessGroup(cfg, G, n_scen)
+    rows = [grp.own_rows(g, n_scen) for g in range(G)]
+    first = None
+    for mode in ("paired", "single", "paired"):
+        monkeypatch.setenv("MRF_PEER_PAIRED", "1" if mode == "paired" else "0")
+        states = [tuple(ref.tensor(np.ascontiguousarray(batch[k][:, r.numpy()])) for k in ("q", "qdot", "params")) for r in rows]
+        avgs = grp.rollout(states)
+        assert [h.comm_info()["paired_blocks"] for h in grp.handles] == [int(mode == "paired")] * G
+        for g, (avg, r) in enumerate(zip(avgs, rows)):
+            r = r.cuda()
+            assert rel(avg, want[r]) < 1e-9 and rel(states[g][0], tq[-1][:, r]) < 1e-9 and rel(states[g][1], tqd[-1][:, r]) < 1e-9
+        res = [(a.clone(), st[0].clone(), st[1].clone()) for a, st in zip(avgs, states)]
+        first = first or res
+        for (a, q, qd), (a0, q0, qd0) in zip(res, first):
+            if mode == "paired":
+                assert torch.equal(a, a0) and torch.equal(q, q0) and torch.equal(qd, qd0)      # the same kernel twice: bit-equal
+            else:
+                assert rel(a, a0) < 1e-12 and rel(q, q0) < 1e-12 and rel(qd, qd0) < 1e-12
     grp.close()
