@@ -78,6 +78,14 @@ __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T*
     T* col = xch + lane;
     const int SX = 8 - m01 - m45;
     __syncthreads();  // the tile is free: the local fold has finished in every lane
+    // the next robot's 21 scalars are requested after this robot's walk (whose registers are free by then) and arrive
+    // under its fold -- held across the WALK they spilled (536 B of scratch)
+    T nxt[MRF_JOINT_STATE_SCALARS];
+    if (nrem > 0) {
+      const int jr0 = remote_robot(0, first, count);
+#pragma unroll
+      for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) nxt[c] = load(jr0, c);
+    }
 #pragma unroll 1
     for (int d = 0; d < nrem; ++d) {
       const int jr = remote_robot(d, first, count);
@@ -85,12 +93,17 @@ __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T*
         T cq[7], sq[7], qd[7];
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-          cq[j] = load(jr, 3 * j + 0);
-          sq[j] = load(jr, 3 * j + 1);
-          qd[j] = load(jr, 3 * j + 2);
+          cq[j] = nxt[3 * j + 0];
+          sq[j] = nxt[3 * j + 1];
+          qd[j] = nxt[3 * j + 2];
         }
         PandaKin<T> K;  // outputs nobody reads: only the hook's stores survive
         panda_walk_own<T, 7>(cfg.mount[jr], cq, sq, qd, K, TileOriginEmit<T>{col, dyn, cfg.jsign, m01, m45});
+      }
+      if (d + 1 < nrem) {
+        const int jn = remote_robot(d + 1, first, count);
+#pragma unroll
+        for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) nxt[c] = load(jn, c);
       }
       pipelined_pairs<T, 9>(
           SX,
