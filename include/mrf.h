@@ -281,6 +281,14 @@ int mrf_step_predict_joints(mrf_handle* h, int64_t n_scenarios, int32_t robot_fi
                             const void* qdot, void* jst_own, void* stream);
 int mrf_step_action_joints(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, const void* q,
                            void* qdot_io, const void* params, const void* jst_all, void* sumsq_io, void* stream);
+/* mrf_step_action_joints of step k AND mrf_step_predict_joints of step k + 1 in one launch: after the solve, q_io += dt *
+ * action and the joint state of the following step (cos q, sin q rotated by the increment as mrf_rollout does, the action
+ * as qdot) goes to jst_next_own [robot_count][21][n_scenarios] -- the block the next all-gather sends.  jst_next_own may be
+ * the rank's own block INSIDE jst_all when nobody else reads it during the launch (a group of one).  What
+ * mrf_rollout_sharded's RCCL transport runs for steps 1 .. H-1. */
+int mrf_step_action_predict_joints(mrf_handle* h, int64_t n_scenarios, int32_t robot_first, int32_t robot_count, void* q_io,
+                                   void* qdot_io, const void* params, const void* jst_all, void* sumsq_io,
+                                   void* jst_next_own, void* stream);
 /* scalars one robot puts on the wire per scenario and step under cfg.exchange: 21, or 9 * mrf_exchange_spheres() */
 int32_t mrf_exchange_scalars(const mrf_handle* h);
 

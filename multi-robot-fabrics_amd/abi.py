@@ -86,7 +86,7 @@ EXPORTS = [
     "mrf_episode_set_pick_place", "mrf_rollout_cartesian_coupled", "mrf_episode_set_rollout", "mrf_rollout_clock", "mrf_episode_set_recorder",
     "mrf_comm_unique_id", "mrf_comm_init", "mrf_comm_peer_open", "mrf_comm_peer_connect", "mrf_comm_partition",
     "mrf_comm_info", "mrf_comm_transport", "mrf_rollout_sharded", "mrf_comm_status", "mrf_comm_reset", "mrf_comm_destroy",
-    "mrf_step_predict_joints", "mrf_step_action_joints", "mrf_exchange_scalars", "mrf_comm_peer_info", "mrf_device_topology",
+    "mrf_step_predict_joints", "mrf_step_action_joints", "mrf_step_action_predict_joints", "mrf_exchange_scalars", "mrf_comm_peer_info", "mrf_device_topology",
     "mrf_comm_peer_local_base", "mrf_comm_peer_connect_local", "mrf_streams_concurrent",
 ]
 
@@ -258,6 +258,9 @@ def load_library(path=None):
         lib.mrf_step_predict_joints.restype = C.c_int
         lib.mrf_step_action_joints.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
         lib.mrf_step_action_joints.restype = C.c_int
+        if hasattr(lib, "mrf_step_action_predict_joints") or not any_abi:
+            lib.mrf_step_action_predict_joints.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+            lib.mrf_step_action_predict_joints.restype = C.c_int
         lib.mrf_exchange_scalars.argtypes = [vp]
         lib.mrf_exchange_scalars.restype = i32
         lib.mrf_comm_peer_info.argtypes = [vp, C.POINTER(i32), i32]

@@ -1363,17 +1363,21 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     if (int rc = mrf_step_prepare(h, n_scen, first, count, q_io, qdot_io, params, c->prm_work, st)) return rc;
     params = c->prm_work;
   }
+  // joint payload: the action kernel of step k also does the position update of step k + 1 and writes its joint state into
+  // the send block (one launch per step; MRF_STEP_UNFUSED=1 keeps the two launches for A/B runs)
+  const bool fuse_next = joints && !std::getenv("MRF_STEP_UNFUSED");
   for (int k = 0; k < H; ++k) {
-    if (int rc = joints ? mrf_step_predict_joints(h, n_scen, first, count, q_io, qdot_io, own, st)
-                        : mrf_step_predict(h, n_scen, first, count, q_io, qdot_io, own, st))
-      return rc;
+    if (k == 0 || !fuse_next)
+      if (int rc = joints ? mrf_step_predict_joints(h, n_scen, first, count, q_io, qdot_io, own, st)
+                          : mrf_step_predict(h, n_scen, first, count, q_io, qdot_io, own, st))
+        return rc;
     if (c->nccl) {
       ncclResult_t r = rccl().AllGather(own, c->sph_pad, per_rank, h->cfg.scalar == MRF_F64 ? ncclDouble : ncclFloat,
                                         c->nccl, st);
       if (r != ncclSuccess) return fail(h, MRF_E_LAUNCH, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
     }
     if (int rc = joints ? mrf_host::step_action_joints_slots(h, n_scen, first, count, q_io, qdot_io, params, c->sph_pad, slots,
-                                                             c->sumsq, st)
+                                                             c->sumsq, fuse_next && k + 1 < H ? own : nullptr, st)
                         : mrf_host::step_action_slots(h, n_scen, first, count, q_io, qdot_io, params, c->sph_pad, slots, c->sumsq, st))
       return rc;
   }

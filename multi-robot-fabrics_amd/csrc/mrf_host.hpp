@@ -160,10 +160,11 @@ int dispatch(mrf_handle* h, F f) {  // f(scalar tag, leaf-set tag)
 int step_action_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
                       void* qdot_io, const void* params, const void* sph_all, const int32_t* robot_slot, void* sumsq_io,
                       void* stream);
-// mrf_step_action_joints with an explicit robot -> block-position map of jst_all (mrf_shard_step.hip); NULL = identity
-int step_action_joints_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
+// mrf_step_action_joints with an explicit robot -> block-position map of jst_all (mrf_shard_step.hip); NULL = identity.
+// jst_next_own != NULL: also the position update of the following step, its joint state -> jst_next_own (then q is written)
+int step_action_joints_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, void* q,
                              void* qdot_io, const void* params, const void* jst_all, const int32_t* robot_slot,
-                             void* sumsq_io, void* stream);
+                             void* sumsq_io, void* jst_next_own, void* stream);
 // the cooperative (one wave per scenario) form of mrf_rollout_cartesian_coupled (mrf_kernels.hip); returns 1 when it does not
 // apply (batch above the crossover, kernel_select = 1, a single robot)
 bool coop_applies(const mrf_handle* h, int64_t n_scen);  // the batch-size / kernel_select rule of the coupled entry points

@@ -9,9 +9,16 @@
 //                           robots of other ranks are re-walked from the gathered joint states (mrf_shard.hpp).  The own
 //                           cos q / sin q / qdot are read back from the gathered array, so the step costs no sincos.
 //
+//   k_step_action_joints<.., NEXT = true> (mrf_step_action_predict_joints) also does the position update of the FOLLOWING step
+//                           and writes its joint state into the rank's send block: one launch per step instead of two (what
+//                           the RCCL transport's loop runs; the update uses the fused kernel's incremental rotation of
+//                           cos q / sin q, so it costs no sincos either).
+//
 // The sphere payload of the same step is k_step_predict / k_step_action in mrf_kernels.hip (everything through memory:
 // the literal "all-gather of sphere centres").
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "mrf_device.hpp"
 #include "mrf_host.hpp"
@@ -51,11 +58,13 @@ struct JointSlots {
   int s[MRF_MAX_ROBOTS];  // position of robot j's [21][B] block in jst_all (identity, or the padded gather layout)
 };
 
-template <typename T, class LS, bool LO, int XK>
+// jst_all and jst_next are NOT restrict: a group of one rank gathers in place (its send block is the gathered array; every
+// lane then reads its own robot's 21 scalars at the start and overwrites exactly those at the end).
+template <typename T, class LS, bool LO, int XK, bool NEXT>
 __global__ __launch_bounds__(64) void k_step_action_joints(const DevCfg<T>* __restrict__ cfgp, int64_t n_scen, int first,
-                                                            int count, const T* __restrict__ q, T* __restrict__ qd_io,
-                                                            const T* __restrict__ prm, const T* __restrict__ jst_all,
-                                                            JointSlots slots, T* __restrict__ sumsq_io) {
+                                                            int count, T* __restrict__ q_io, T* __restrict__ qd_io,
+                                                            const T* __restrict__ prm, const T* jst_all, JointSlots slots,
+                                                            T* __restrict__ sumsq_io, T* jst_next) {
   __shared__ T xch[LO ? TILE_SCALARS : GEN_SCALARS];
   constexpr bool REMOTE = XK != XK_NONE;
   const DevCfg<T>& cfg = *cfgp;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(64) void k_step_action_joints(const DevCfg<T>* __re
     const T* own = jst_all + ((int64_t)slots.s[me] * MRF_JOINT_STATE_SCALARS) * n_scen + scen;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-      R.q[j] = q[j * rows + row];
+      R.q[j] = q_io[j * rows + row];
       R.cq[j] = own[(int64_t)(3 * j + 0) * n_scen];
       R.sq[j] = own[(int64_t)(3 * j + 1) * n_scen];
       R.qd[j] = own[(int64_t)(3 * j + 2) * n_scen];
@@ -106,6 +115,42 @@ __global__ __launch_bounds__(64) void k_step_action_joints(const DevCfg<T>* __re
     }
     sumsq_io[row] += ss;
   }
+  if constexpr (NEXT) {
+    // system_step 'vel' of the following step (FPJ:77-80) as k_rollout_panda does it: q += dt * action, cos q / sin q
+    // rotated by the increment where every lane's is small (a wave-wide vote), else recomputed
+    T dq[7];
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      dq[j] = cfg.dt * act[j];
+      small = small && (m_abs(dq[j]) < T(0.125));
+      R.q[j] += dq[j];
+    }
+    if (__all(small)) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        T sd, cd;
+        small_sincos(dq[j], sd, cd);
+        const T c = R.cq[j] * cd - R.sq[j] * sd;
+        const T s = R.sq[j] * cd + R.cq[j] * sd;
+        R.cq[j] = c;
+        R.sq[j] = s;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
+    }
+    if (active) {
+      T* dst = jst_next + ((int64_t)l * MRF_JOINT_STATE_SCALARS) * n_scen + scen;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        q_io[j * rows + row] = R.q[j];
+        dst[(int64_t)(3 * j + 0) * n_scen] = R.cq[j];
+        dst[(int64_t)(3 * j + 1) * n_scen] = R.sq[j];
+        dst[(int64_t)(3 * j + 2) * n_scen] = act[j];
+      }
+    }
+  }
 }
 
 }  // namespace mrf
@@ -116,9 +161,9 @@ using mrf_host::fail;
 using mrf_host::is_link_origin_table;
 using mrf_host::launch;
 
-int mrf_host::step_action_joints_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
+int mrf_host::step_action_joints_slots(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, void* q,
                                        void* qdot_io, const void* params, const void* jst_all, const int32_t* robot_slot,
-                                       void* sumsq_io, void* stream) {
+                                       void* sumsq_io, void* jst_next_own, void* stream) {
   MRF_CHECK_READY(h);
   if (h->cfg.model != MRF_MODEL_PANDA7 || h->cfg.mode != MRF_MODE_VEL)
     return fail(h, MRF_E_CONFIG, "sharded rollout needs the panda7 model in mode 'vel'");
@@ -137,10 +182,19 @@ int mrf_host::step_action_joints_slots(mrf_handle* h, int64_t n_scen, int32_t ro
     using LS = decltype(cl);
     auto go = [&](auto kernel) {
       return launch(h, kernel, grid, block, st, (const mrf::DevCfg<T>*)h->dcfg, n_scen, (int)robot_first, (int)robot_count,
-                    (const T*)q, (T*)qdot_io, (const T*)params, (const T*)jst_all, slots, (T*)sumsq_io);
+                    (T*)q, (T*)qdot_io, (const T*)params, (const T*)jst_all, slots, (T*)sumsq_io, (T*)jst_next_own);
     };
-    if (all) return lo ? go(mrf::k_step_action_joints<T, LS, true, mrf::XK_NONE>) : go(mrf::k_step_action_joints<T, LS, false, mrf::XK_NONE>);
-    return lo ? go(mrf::k_step_action_joints<T, LS, true, mrf::XK_JOINTS>) : go(mrf::k_step_action_joints<T, LS, false, mrf::XK_JOINTS>);
+    auto pick = [&](auto lo_c, auto xk_c) {
+      constexpr bool LO = decltype(lo_c)::value;
+      constexpr int XK = decltype(xk_c)::value;
+      return jst_next_own ? go(mrf::k_step_action_joints<T, LS, LO, XK, true>) : go(mrf::k_step_action_joints<T, LS, LO, XK, false>);
+    };
+    using std::integral_constant;
+    if (all)
+      return lo ? pick(integral_constant<bool, true>{}, integral_constant<int, mrf::XK_NONE>{})
+                : pick(integral_constant<bool, false>{}, integral_constant<int, mrf::XK_NONE>{});
+    return lo ? pick(integral_constant<bool, true>{}, integral_constant<int, mrf::XK_JOINTS>{})
+              : pick(integral_constant<bool, false>{}, integral_constant<int, mrf::XK_JOINTS>{});
   });
 }
 
@@ -170,8 +224,16 @@ int mrf_step_predict_joints(mrf_handle* h, int64_t n_scen, int32_t robot_first, 
 
 int mrf_step_action_joints(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, const void* q,
                            void* qdot_io, const void* params, const void* jst_all, void* sumsq_io, void* stream) {
-  return mrf_host::step_action_joints_slots(h, n_scen, robot_first, robot_count, q, qdot_io, params, jst_all, nullptr, sumsq_io,
-                                            stream);
+  return mrf_host::step_action_joints_slots(h, n_scen, robot_first, robot_count, const_cast<void*>(q), qdot_io, params, jst_all,
+                                            nullptr, sumsq_io, nullptr, stream);  // NEXT = false never writes q
+}
+
+int mrf_step_action_predict_joints(mrf_handle* h, int64_t n_scen, int32_t robot_first, int32_t robot_count, void* q_io,
+                                   void* qdot_io, const void* params, const void* jst_all, void* sumsq_io, void* jst_next_own,
+                                   void* stream) {
+  if (h && !jst_next_own) return fail(h, MRF_E_ARG, "jst_next_own is NULL (mrf_step_action_joints is the step without the update)");
+  return mrf_host::step_action_joints_slots(h, n_scen, robot_first, robot_count, q_io, qdot_io, params, jst_all, nullptr, sumsq_io,
+                                            jst_next_own, stream);
 }
 
 }  // extern "C"

@@ -311,6 +311,19 @@ class FabricHandle:
                                              self._arg(sumsq_io, (rows,), "sumsq_io"), self._stream(stream))
         self._check(rc)
 
+    def step_action_predict_joints(self, n_scen, robot_first, robot_count, q_io, qdot_io, params, jst_all, sumsq_io, jst_next_own,
+                                   stream=None):
+        """step_action_joints of this step AND step_predict_joints of the following one in one launch: q_io += dt * action,
+        the next joint state -> jst_next_own [count, 21, n_scen] (the block the next all-gather sends)."""
+        rows = n_scen * robot_count
+        rc = self.lib.mrf_step_action_predict_joints(
+            self._h, n_scen, robot_first, robot_count, self._arg(q_io, (self.dof, rows), "q_io"),
+            self._arg(qdot_io, (self.dof, rows), "qdot_io"), self._arg(params, (abi.NPARAM, rows), "params"),
+            self._arg(jst_all, (self.cfg.n_robots, abi.JOINT_STATE_SCALARS, n_scen), "jst_all"),
+            self._arg(sumsq_io, (rows,), "sumsq_io"),
+            self._arg(jst_next_own, (robot_count, abi.JOINT_STATE_SCALARS, n_scen), "jst_next_own"), self._stream(stream))
+        self._check(rc)
+
     # ------------------------------------------------------------------ host-buffer entry points (numpy in, numpy out)
     @staticmethod
     def _host(a, shape, name):

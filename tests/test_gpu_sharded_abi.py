@@ -216,7 +216,9 @@ def test_virtual_ranks_step_kernels_random_configurations(seed):
     want_avg, tq, tqd = ref.rollout(t(batch["q"]), t(batch["qdot"]), t(batch["params"]), want_traj=True)
     G = int(rng.integers(1, N + 1))
     parts = sharded.robot_partition(N, G)
-    for exchange in (abi.EXCHANGE_JOINTS, abi.EXCHANGE_SPHERES):
+    # fused: mrf_step_action_predict_joints -- the action of step k and the position update + joint state of step k + 1 in one
+    # launch, every rank into a send block of its own, gathered afterwards (what the RCCL transport's loop runs)
+    for exchange, fused in ((abi.EXCHANGE_JOINTS, False), (abi.EXCHANGE_JOINTS, True), (abi.EXCHANGE_SPHERES, False)):
         h = ref
         S = h.exchange_spheres
         shape = (21,) if exchange == abi.EXCHANGE_JOINTS else (S, 9)
@@ -228,22 +230,27 @@ def test_virtual_ranks_step_kernels_random_configurations(seed):
                 prm = h.step_prepare(B, first, count, q, qd, prm)
             state.append(dict(rows=rows, q=q, qd=qd, prm=prm, ss=torch.zeros((B * count,), dtype=torch.float64, device="cuda")))
         everybody = torch.zeros((N,) + shape + (B,), dtype=torch.float64, device="cuda")
-        for _ in range(H):
-            for (first, count), st in zip(parts, state):          # every rank predicts, the "gather" is the shared array
-                if exchange == abi.EXCHANGE_JOINTS:
+        send = [torch.zeros((count, 21, B), dtype=torch.float64, device="cuda") for _, count in parts] if fused else None
+        for k in range(H):
+            for g, ((first, count), st) in enumerate(zip(parts, state)):   # every rank predicts, the "gather" is the shared array
+                if fused and k > 0:
+                    everybody[first:first + count] = send[g]               # ... or the copy of what its last action launch sent
+                elif exchange == abi.EXCHANGE_JOINTS:
                     h.step_predict_joints(B, first, count, st["q"], st["qd"], everybody[first:first + count])
                 else:
                     h.step_predict(B, first, count, st["q"], st["qd"], everybody[first:first + count])
-            for (first, count), st in zip(parts, state):
-                if exchange == abi.EXCHANGE_JOINTS:
+            for g, ((first, count), st) in enumerate(zip(parts, state)):
+                if fused and k + 1 < H:
+                    h.step_action_predict_joints(B, first, count, st["q"], st["qd"], st["prm"], everybody, st["ss"], send[g])
+                elif exchange == abi.EXCHANGE_JOINTS:
                     h.step_action_joints(B, first, count, st["q"], st["qd"], st["prm"], everybody, st["ss"])
                 else:
                     h.step_action(B, first, count, st["q"], st["qd"], st["prm"], everybody, st["ss"])
         torch.cuda.synchronize()
         for st in state:
             rows = torch.from_numpy(st["rows"]).cuda()
-            assert rel(st["ss"] / (H * 7), want_avg[rows]) < 1e-9, (seed, N, G, table, exchange)
-            assert rel(st["q"], tq[-1][:, rows]) < 1e-9 and rel(st["qd"], tqd[-1][:, rows]) < 1e-9, (seed, N, G, table, exchange)
+            assert rel(st["ss"] / (H * 7), want_avg[rows]) < 1e-9, (seed, N, G, table, exchange, fused)
+            assert rel(st["q"], tq[-1][:, rows]) < 1e-9 and rel(st["qd"], tqd[-1][:, rows]) < 1e-9, (seed, N, G, table, exchange, fused)
 
 
 @pytest.mark.parametrize("exchange", ["joints", "spheres"])

@@ -16,7 +16,7 @@ rows=$(python3 -c "import json; print(json.load(open('$root/gpurun_out/prof_kern
 k=$root/gpurun_out/profiles/${tag}_kernels_pmc.json
 t=$root/gpurun_out/profiles/${tag}_sharded_traffic.json
 python3 tools/make_traffic.py $k sharded_rccl_spheres_f64 --rows $rows --sum-kernels "k_step_predict<" "k_step_action<" --steps-per-launch 1 --out $t > /dev/null
-python3 tools/make_traffic.py $k sharded_rccl_joints_f64 --rows $rows --sum-kernels "k_step_predict_joints<" "k_step_action_joints<" --steps-per-launch 1 --out $t > /dev/null
+python3 tools/make_traffic.py $k sharded_rccl_joints_f64 --rows $rows --sum-kernels "k_step_action_joints<" --steps-per-launch 1 --out $t > /dev/null
 # a group of one exchanges nothing: the same persistent kernel (XK_NONE) whatever the configured payload
 python3 tools/make_traffic.py $k sharded_peer_joints_f64 --rows $rows --sum-kernels "k_rollout_peer<" --steps-per-launch 30 --out $t > /dev/null
 python3 tools/make_traffic.py $k sharded_peer_spheres_f64 --rows $rows --sum-kernels "k_rollout_peer<" --steps-per-launch 30 --out $t > /dev/null

@@ -48,8 +48,8 @@ mt(c32, f"config_CART32_f64_B{size(2)}", "--horizon", "30", "--kernel-substring"
 mt(c32, f"config_CARTC32_f64_B{size(2)}", "--horizon", "30", "--kernel-substring", "k_rollout_carts_panda<")
 k = f"profiles/{tag}_kernels_pmc.json"
 mt(k, "sharded_rccl_spheres_f64", "--rows", str(rows), "--sum-kernels", "k_step_predict<", "k_step_action<", "--steps-per-launch", "1")
-mt(k, "sharded_rccl_joints_f64", "--rows", str(rows), "--sum-kernels", "k_step_predict_joints<", "k_step_action_joints<",
-   "--steps-per-launch", "1")
+mt(k, "sharded_rccl_joints_f64", "--rows", str(rows), "--sum-kernels", "k_step_action_joints<",
+   "--steps-per-launch", "1")   # the loop's one launch per step (action + next predict); the first step's predict is 1 of 30
 # a group of one exchanges nothing: the same persistent kernel (XK_NONE) whatever the configured payload
 mt(k, "sharded_peer_joints_f64", "--rows", str(rows), "--sum-kernels", "k_rollout_peer<", "--steps-per-launch", "30")
 mt(k, "sharded_peer_spheres_f64", "--rows", str(rows), "--sum-kernels", "k_rollout_peer<", "--steps-per-launch", "30")

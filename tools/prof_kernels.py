@@ -81,8 +81,11 @@ qq = q.clone()
 report("k_step_predict_joints", timed(lambda: h.step_predict_joints(B, 0, N, qq, qqd, jst)), rows, sb * (21 + 21), "rows")
 qq = q.clone()
 h.step_predict_joints(B, 0, N, qq, qqd, jst)
-report("k_step_action_joints (all robots local)", timed(lambda: h.step_action_joints(B, 0, N, qq, qd.clone(), prm, jst, ssq)), rows,
-       sb * (7 + 21 + 29 + 8), "rows")
+# the launch the RCCL transport's loop runs for steps 0 .. H-2: the action AND the following step's position update + joint state
+# (into the rank's send block: a group of one gathers in place)
+qd_run = qd.clone()
+report("k_step_action_joints + next step's predict (all robots local)",
+       timed(lambda: h.step_action_predict_joints(B, 0, N, qq, qd_run, prm, jst, ssq, jst)), rows, sb * (7 + 21 + 29 + 8 + 7 + 21), "rows")
 # the peer transport's persistent kernel with a group of one (round 6: all robots on this GPU exchange on chip -- the fused
 # kernel's step inside the persistent block loop, staging + commit passes around it)
 from multi_robot_fabrics_amd.sharded import ShardedRollout
