@@ -358,8 +358,10 @@ int mrf_comm_partition(const mrf_handle* h, int32_t* robot_first, int32_t* robot
  *   13 workgroups of the persistent PEER kernel's footprint found CO-RESIDENT on this device by the roll call of
  *      mrf_comm_peer_connect -- the cap of that kernel's grid (0: not measured: a group of one, or ranks sharing a device)
  *   14 the last mrf_rollout_sharded of the PEER transport walked its blocks in PAIRS (k_rollout_peer_paired: joint payload,
- *      more blocks than workgroup slots; the exchange of one block runs under the step of the other) */
-#define MRF_COMM_INFO_N 15
+ *      more blocks than workgroup slots; the exchange of one block runs under the step of the other)
+ *   15 the PEER communicator exchanges TAGGED payload words (opt-in MRF_PEER_TAGGED=1 at mrf_comm_peer_open: every 32 bits
+ *      of joint state in one 8-byte store with the tag of its step, polled by the reader; no flags; twice the link bytes) */
+#define MRF_COMM_INFO_N 16
 int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n);
 int32_t mrf_comm_transport(const mrf_handle* h);
 /* Where the exchange buffers of a connected PEER communicator really are, per rank g of the group: out[g*MRF_PEER_INFO_N + i]

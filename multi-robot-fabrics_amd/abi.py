@@ -98,7 +98,7 @@ JOINT_STATE_SCALARS = 21
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
 COMM_INFO_KEYS = ("transport", "rank", "world", "robot_first", "robot_count", "rccl_comm_count", "rccl_user_rank",
                   "rccl_device", "hip_device", "peer_buffers_mapped", "exchange", "exchange_scalars_per_robot",
-                  "peers_one_hop", "coresident_workgroups", "paired_blocks")
+                  "peers_one_hop", "coresident_workgroups", "paired_blocks", "tagged_payload")
 PEER_INFO_KEYS = ("device", "can_access_peer", "link_type", "hops")
 LINK_TYPE_NAMES = {0: "same device", 1: "hypertransport", 2: "pcie", 3: "qpi", 4: "xgmi", -1: "unknown"}
 

@@ -43,6 +43,7 @@ struct PeerView {
   long long b_max;                      // scenario capacity of the buffers
   long long off_flags, off_err, off_x;  // byte offsets inside an allocation
   long long timeout_ticks;              // bounded spin, in wall_clock64 ticks
+  int tagged;                           // the payload region holds tagged words (XK_JOINTS_TAGGED), twice the bytes
 };
 
 // flags: [2 generations][G source ranks][nblk_max]   payload: [2][n_robots][xs][b_max]
@@ -67,6 +68,116 @@ __device__ __forceinline__ void xstore(T* p, T v) {
 template <typename T>
 __device__ __forceinline__ T xload(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// TAGGED payload (XK_JOINTS_TAGGED, opt-in MRF_PEER_TAGGED=1; round 6): every 32 bits of payload travel in ONE 8-byte store
+// together with a 32-bit tag of the step they belong to (the low-latency protocol of the collective libraries): the reader
+// polls the payload words themselves until all carry the tag it expects.  No store drain before a flag, no flag, no poll
+// round trip in front of the payload loads -- at twice the bytes on the link, so for the latency-bound batch range.
+// 8-byte stores and loads are single-copy atomic, so a word is either the old or the new (value half, tag) pair.
+// tag(seq): sequence number + reset epoch * an odd constant (a late store of the previous epoch cannot pass for any step the
+// new epoch will reach), never 0 (the buffer is zeroed at creation and at every reset).
+using tagged_word = unsigned long long;
+__device__ __forceinline__ unsigned tagged_tag(unsigned long long seq) {
+  const unsigned t = (unsigned)seq + (unsigned)(seq >> 40) * 0x9E3779B1u;
+  return t ? t : 0x80000000u;
+}
+template <typename T>
+constexpr int kTaggedWords = (int)(sizeof(T) / 4);  // words per scalar
+// word w of scalar c of robot `robot`, scenario `scen`:  [2 generations][n_robots][21][W][b_max]
+template <typename T>
+__device__ __forceinline__ tagged_word* peer_tagged(const PeerView& V, int dst, int gen, int n_robots, int robot, int c, int w,
+                                                    long long scen) {
+  constexpr int W = kTaggedWords<T>;
+  return reinterpret_cast<tagged_word*>(V.base[dst] + V.off_x) +
+         ((((size_t)gen * n_robots + robot) * MRF_JOINT_STATE_SCALARS + c) * W + w) * (size_t)V.b_max + scen;
+}
+template <typename T>
+__device__ __forceinline__ void tagged_store(const PeerView& V, int dst, int gen, int n_robots, int robot, int c, long long scen,
+                                             T v, unsigned tag) {
+  if constexpr (sizeof(T) == 8) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    __hip_atomic_store(peer_tagged<T>(V, dst, gen, n_robots, robot, c, 0, scen), (b & 0xffffffffull) | ((tagged_word)tag << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(peer_tagged<T>(V, dst, gen, n_robots, robot, c, 1, scen), (b >> 32) | ((tagged_word)tag << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    __hip_atomic_store(peer_tagged<T>(V, dst, gen, n_robots, robot, c, 0, scen),
+                       (tagged_word)__builtin_bit_cast(unsigned, v) | ((tagged_word)tag << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// One attempt at the 21 scalars of `robot` in the LOCAL buffer: all words requested at once; true when every word carries `tag`.
+template <typename T>
+__device__ __forceinline__ bool tagged_try_load(const PeerView& V, int gen, int n_robots, int robot, long long scen, unsigned tag,
+                                                T (&v)[MRF_JOINT_STATE_SCALARS]) {
+  constexpr int W = kTaggedWords<T>;
+  tagged_word w[MRF_JOINT_STATE_SCALARS][W];
+#pragma unroll
+  for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c)
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+      w[c][k] = __hip_atomic_load(peer_tagged<T>(V, V.grank, gen, n_robots, robot, c, k, scen), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM);
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) ok = ok && (unsigned)(w[c][k] >> 32) == tag;
+    if constexpr (W == 2)
+      v[c] = __builtin_bit_cast(T, (w[c][0] & 0xffffffffull) | (w[c][1] << 32));
+    else
+      v[c] = __builtin_bit_cast(T, (unsigned)w[c][0]);
+  }
+  return ok;
+}
+// ... until they all do (bounded like the flag wait: the group's error word, the time-out, the post-mortem)
+template <typename T>
+__device__ __forceinline__ void tagged_load_robot(const PeerView& V, int gen, int n_robots, int robot, long long scen, bool active,
+                                                  unsigned long long seq, int blk, const int* err, int etag, int lane,
+                                                  bool& broken_seen, T (&v)[MRF_JOINT_STATE_SCALARS]) {
+  const unsigned tag = tagged_tag(seq);
+  const long long t0 = wall_clock64();
+  int tries = 0;
+#pragma unroll 1
+  for (;; ++tries) {  // one copy of the 42 loads: the first attempt is the loop's first pass
+    const bool ok = tagged_try_load<T>(V, gen, n_robots, robot, scen, tag, v);
+    if (__all(ok || !active) || broken_seen) return;
+    // the error word (an uncached round trip of its own) and the clock only every 16th miss: a miss is usually a payload
+    // that is a microsecond away
+    if ((tries & 15) != 15) {
+      if (tries < 8)
+        __builtin_amdgcn_s_sleep(4);
+      else
+        __builtin_amdgcn_s_sleep(32);
+      continue;
+    }
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == etag) break;
+    if (wall_clock64() - t0 > V.timeout_ticks) {
+      if (lane == 0) {
+        int* dbg = reinterpret_cast<int*>(V.base[V.grank] + V.off_err);
+        if (atomicCAS(dbg + 1, 0, 1) == 0) {
+          dbg[2] = blk;
+          dbg[3] = -1 - robot;  // tagged payload: the ROBOT whose joint state did not arrive (negative: not a rank)
+          dbg[4] = (int)(seq & 0x7fffffff);
+          dbg[5] = 0;
+          dbg[6] = (int)blockIdx.x;
+          dbg[7] = (int)gridDim.x;
+        }
+        for (int g = 0; g < V.G; ++g)
+          __hip_atomic_store(reinterpret_cast<int*>(V.base[g] + V.off_err), etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      break;
+    }
+  }
+  broken_seen = true;  // the group is in error: nothing more is published by this wave, the commit pass discards the rollout
+}
+
+// the 21 scalars of robot jr for this lane's scenario out of the LOCAL buffer (flag protocol: the flags were awaited before)
+template <typename T>
+__device__ __forceinline__ void xload_robot(const T* xloc, int jr, long long b_max, long long scen, T (&v)[MRF_JOINT_STATE_SCALARS]) {
+#pragma unroll
+  for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) v[c] = xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * b_max + scen);
 }
 
 // a quiet NaN by bit pattern (this translation unit is compiled -ffast-math, where NaN literals are undefined)
@@ -295,6 +406,21 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
 #pragma unroll
       for (int j = 0; j < 7; ++j) m_sincos(R.q[j], &R.sq[j], &R.cq[j]);
     }
+    if constexpr (XK == XK_JOINTS_TAGGED) {
+      // ---- publish: tagged words, no drain, no flag (see tagged_store)
+      if (exchanging && active && !broken_seen) {
+        const unsigned tag = tagged_tag(seq);
+        for (int g = 0; g < V.G; ++g) {
+          if (g == V.grank) continue;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            tagged_store<T>(V, g, gen, N, me, 3 * j + 0, scen, R.cq[j], tag);
+            tagged_store<T>(V, g, gen, N, me, 3 * j + 1, scen, R.sq[j], tag);
+            tagged_store<T>(V, g, gen, N, me, 3 * j + 2, scen, R.qd[j], tag);
+          }
+        }
+      }
+    }
     if constexpr (XK == XK_JOINTS) {
       // ---- publish: the joint state of step k goes out BEFORE the own chain walk, so that the flag round trip runs
       // under the walk and the local fold (FPJ:211-225 across GPUs; the receivers re-walk this chain)
@@ -365,14 +491,21 @@ __global__ __launch_bounds__(64) void k_rollout_peer(const DevCfg<T>* __restrict
           }
         },
         [&]() {
-          if (exchanging) MRF_TM(tm_wait, peer_wait_flags(V, gen, blk, seq, err, etag, lane, broken_seen))
+          if constexpr (XK != XK_JOINTS_TAGGED)
+            if (exchanging) MRF_TM(tm_wait, peer_wait_flags(V, gen, blk, seq, err, etag, lane, broken_seen))
         },
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           if constexpr (XK == XK_JOINTS) {
             MRF_TM(tm_remote, remote_obstacles_joints<typename LS::Collision, LO>(
                 cfg, xch, lane, first, count, N,
-                [&](int jr, int c) { return xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * V.b_max + scen); }, E, acc,
-                &tm_stage))
+                [&](int jr, T (&v)[MRF_JOINT_STATE_SCALARS]) { xload_robot(xloc, jr, V.b_max, scen, v); }, E, acc, &tm_stage))
+          } else if constexpr (XK == XK_JOINTS_TAGGED) {
+            MRF_TM(tm_remote, remote_obstacles_joints<typename LS::Collision, LO, false>(
+                cfg, xch, lane, first, count, N,
+                [&](int jr, T (&v)[MRF_JOINT_STATE_SCALARS]) {
+                  tagged_load_robot<T>(V, gen, N, jr, scen, active, seq, blk, err, etag, lane, broken_seen, v);
+                },
+                E, acc, &tm_stage))
           } else if constexpr (XK == XK_SPHERES) {
             const int SX = cfg.n_spheres - m01 - m45;
             MRF_TM(tm_remote, remote_obstacles_spheres<typename LS::Collision, LO>(
@@ -599,8 +732,7 @@ __global__ __launch_bounds__(64) void k_rollout_peer_paired(const DevCfg<T>* __r
         [&](const EgoPts<T, NG>& E, EgoAcc<T, NG>& acc) {
           MRF_TM(tm_remote, remote_obstacles_joints<typename LS::Collision, LO>(
               cfg, xch, lane, first, count, N,
-              [&](int jr, int c) { return xload(xloc + ((size_t)jr * MRF_JOINT_STATE_SCALARS + c) * V.b_max + scen); }, E, acc,
-              &tm_stage))
+              [&](int jr, T (&v)[MRF_JOINT_STATE_SCALARS]) { xload_robot(xloc, jr, V.b_max, scen, v); }, E, acc, &tm_stage))
         },
         qdd, act);
 #pragma unroll
@@ -813,6 +945,7 @@ struct Comm {
   void* swap = nullptr;   // paired blocks (joint payload): the resting block's state, [swap_wgs][32][64] scalars
   unsigned swap_wgs = 0;
   bool last_paired = false;  // the last rollout walked its blocks two at a time (MRF_PEER_DEBUG prints it)
+  bool tagged = false;       // MRF_PEER_TAGGED=1 at mrf_comm_peer_open: tagged payload words (XK_JOINTS_TAGGED), twice the bytes
   unsigned grid_cap = 0;   // co-resident workgroups measured by the roll call at connect (0: not measured -- a group of one,
                            // or ranks sharing a device in tests)
   unsigned long long epoch = 0;  // mrf_comm_reset count: the high bits of every sequence number
@@ -989,7 +1122,7 @@ int mrf_comm_info(const mrf_handle* h, int32_t* out, int32_t n) {
       c ? c->transport : MRF_TRANSPORT_NONE, c ? c->rank : 0, c ? c->world : 0, c ? c->first[c->rank] : 0,
       c ? c->first[c->rank + 1] - c->first[c->rank] : 0, c ? c->nccl_count : 0, c ? c->nccl_rank : -1,
       c ? c->nccl_device : -1, h->device, c && c->transport == MRF_TRANSPORT_PEER && c->connected ? c->world - 1 : 0,
-      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop, c ? (int32_t)c->grid_cap : 0, c && c->last_paired ? 1 : 0};
+      h->cfg.exchange, c ? c->xs : mrf_exchange_scalars(h), one_hop, c ? (int32_t)c->grid_cap : 0, c && c->last_paired ? 1 : 0, c && c->tagged ? 1 : 0};
   for (int i = 0; i < n && i < MRF_COMM_INFO_N; ++i) out[i] = vals[i];
   return MRF_OK;
 }
@@ -1011,7 +1144,10 @@ int mrf_comm_peer_open(mrf_handle* h, int32_t rank, int32_t world, int64_t max_s
   c->off_flags = 0;
   c->off_err = ((size_t)2 * world * c->nblk_max * sizeof(unsigned long long) + 255) & ~(size_t)255;
   c->off_x = c->off_err + 256;
-  c->bytes = c->off_x + (size_t)2 * h->cfg.n_robots * c->xs * c->b_max * scalar_bytes(h);
+  // opt-in (the same on every rank of a group): the joint payload travels as tagged words -- see tagged_store
+  const char* tg = std::getenv("MRF_PEER_TAGGED");
+  c->tagged = tg && std::atoi(tg) == 1 && world > 1 && c->xs == MRF_JOINT_STATE_SCALARS;
+  c->bytes = c->off_x + (size_t)2 * h->cfg.n_robots * c->xs * c->b_max * scalar_bytes(h) * (c->tagged ? 2 : 1);
   // fine-grained device memory: coherent for the peers' stores and this GPU's loads while kernels are running
   hipError_t e = hipExtMallocWithFlags((void**)&c->local, c->bytes, hipDeviceMallocFinegrained);
   if (e == hipSuccess) e = hipMemset(c->local, 0, c->bytes);
@@ -1239,6 +1375,7 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     V.off_flags = (long long)c->off_flags;
     V.off_err = (long long)c->off_err;
     V.off_x = (long long)c->off_x;
+    V.tagged = c->tagged ? 1 : 0;
     int rate_khz = 100000;
     (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, h->device);
     const char* env = std::getenv("MRF_PEER_TIMEOUT_MS");
@@ -1287,7 +1424,7 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
     if (const char* pm = std::getenv("MRF_PEER_PAIRED_MIN_BLOCKS"))
       if (std::atoi(pm) >= 2) paired_min = (unsigned)std::atoi(pm);
     const char* pe = std::getenv("MRF_PEER_PAIRED");
-    const bool paired = c->world > 1 && c->xs == MRF_JOINT_STATE_SCALARS && c->swap && nblk >= paired_min && pe && std::atoi(pe) == 1;
+    const bool paired = c->world > 1 && c->xs == MRF_JOINT_STATE_SCALARS && !c->tagged && c->swap && nblk >= paired_min && pe && std::atoi(pe) == 1;
     c->last_paired = paired;
     return dispatch(h, [&](auto t, auto cl) {
       using T = decltype(t);
@@ -1342,6 +1479,8 @@ int mrf_rollout_sharded(mrf_handle* h, int64_t n_scen, void* q_io, void* qdot_io
       if (c->world == 1) return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_NONE>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_NONE>);
       if (paired)
         return lo ? go(mrf::k_rollout_peer_paired<T, LS, true>, (T*)c->swap) : go(mrf::k_rollout_peer_paired<T, LS, false>, (T*)c->swap);
+      if (c->tagged)
+        return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_JOINTS_TAGGED>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_JOINTS_TAGGED>);
       if (c->xs == MRF_JOINT_STATE_SCALARS)
         return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_JOINTS>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_JOINTS>);
       return lo ? go(mrf::k_rollout_peer<T, LS, true, mrf::XK_SPHERES>) : go(mrf::k_rollout_peer<T, LS, false, mrf::XK_SPHERES>);
@@ -1444,6 +1583,9 @@ int mrf_comm_reset(mrf_handle* h) {
     // starts from sequence 1 again, whatever number of rollouts each of them had issued before (a rank that missed a
     // call is the usual reason for the timeout).  The caller's barriers on both sides keep peers from writing meanwhile.
     if (int rc = check_hip(h, hipMemset(c->local + c->off_flags, 0, c->off_x - c->off_flags), "hipMemset")) return rc;
+    // tagged payload: the words are their own flags (a late store of the old epoch carries a tag no step of the new one expects)
+    if (c->tagged)
+      if (int rc = check_hip(h, hipMemset(c->local + c->off_x, 0, c->bytes - c->off_x), "hipMemset")) return rc;
     if (int rc = check_hip(h, hipDeviceSynchronize(), "hipDeviceSynchronize")) return rc;
     // A peer whose stream was still running when this rank cleared its flags may have stored a flag of the OLD
     // sequence afterwards.  Sequence numbers carry the reset count in their high bits, so such a flag is smaller than

@@ -18,7 +18,7 @@
 namespace mrf {
 inline namespace MRF_DEVICE_FLAVOUR {
 
-enum { XK_NONE = 0, XK_JOINTS = 1, XK_SPHERES = 2 };
+enum { XK_NONE = 0, XK_JOINTS = 1, XK_SPHERES = 2, XK_JOINTS_TAGGED = 3 };  // TAGGED: mrf_comm.hip, the peer kernel only
 
 // the d-th robot (d = 0 .. N - count - 1) that is NOT in the owned block [first, first + count)
 __device__ __forceinline__ int remote_robot(int d, int first, int count) { return d < first ? d : d + count; }
@@ -56,13 +56,15 @@ struct TileOriginEmit {
   }
 };
 
-// Fold the spheres of every robot of another rank, re-derived from its exchanged joint state.  load(jr, c) returns scalar
-// c (0..20: cos, sin, qdot of joint c/3) of robot jr for THIS lane's scenario; all 21 loads of a robot are issued before
+// Fold the spheres of every robot of another rank, re-derived from its exchanged joint state.  load_robot(jr, v) fills v with
+// the 21 scalars (cos, sin, qdot of joint c/3) of robot jr for THIS lane's scenario; all 21 loads of a robot are issued before
 // the first is used (one memory round trip per robot), then go to the LDS rows the rolled walk reads by joint index (a
 // runtime index into registers would put them into scratch memory).
-template <class CL, bool LO, typename T, class Load>
+// PREFETCH: (link-origin tables) request the next robot's scalars after this robot's walk, so that they arrive under its fold;
+// false where load_robot is more than 21 loads (the tagged payload's poll loop: 42 words in flight spilled 744 B there).
+template <class CL, bool LO, bool PREFETCH = true, typename T, class LoadRobot>
 __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T* __restrict__ xch, int lane, int first,
-                                                        int count, int N, Load load, const EgoPts<T, NG>& E,
+                                                        int count, int N, LoadRobot load_robot, const EgoPts<T, NG>& E,
                                                         EgoAcc<T, NG>& acc, [[maybe_unused]] long long* tm_stage = nullptr) {
   const int nrem = N - count;
   const bool dyn = cfg.dynamic != 0;
@@ -81,14 +83,11 @@ __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T*
     // the next robot's 21 scalars are requested after this robot's walk (whose registers are free by then) and arrive
     // under its fold -- held across the WALK they spilled (536 B of scratch)
     T nxt[MRF_JOINT_STATE_SCALARS];
-    if (nrem > 0) {
-      const int jr0 = remote_robot(0, first, count);
-#pragma unroll
-      for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) nxt[c] = load(jr0, c);
-    }
+    if (PREFETCH && nrem > 0) load_robot(remote_robot(0, first, count), nxt);
 #pragma unroll 1
     for (int d = 0; d < nrem; ++d) {
       const int jr = remote_robot(d, first, count);
+      if (!PREFETCH) load_robot(jr, nxt);
       {
         T cq[7], sq[7], qd[7];
 #pragma unroll
@@ -100,11 +99,7 @@ __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T*
         PandaKin<T> K;  // outputs nobody reads: only the hook's stores survive
         panda_walk_own<T, 7>(cfg.mount[jr], cq, sq, qd, K, TileOriginEmit<T>{col, dyn, cfg.jsign, m01, m45});
       }
-      if (d + 1 < nrem) {
-        const int jn = remote_robot(d + 1, first, count);
-#pragma unroll
-        for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) nxt[c] = load(jn, c);
-      }
+      if (PREFETCH && d + 1 < nrem) load_robot(remote_robot(d + 1, first, count), nxt);
       pipelined_pairs<T, 9>(
           SX,
           [&](int m, T (&sp)[9]) {
@@ -132,8 +127,7 @@ __device__ __forceinline__ void remote_obstacles_joints(const DevCfg<T>& cfg, T*
     for (int dd = 0; dd < nch; ++dd) {
       const int jr = remote_robot(d0 + dd, first, count);
       T v[MRF_JOINT_STATE_SCALARS];
-#pragma unroll
-      for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) v[c] = load(jr, c);
+      load_robot(jr, v);
 #pragma unroll
       for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c) stage[(dd * MRF_JOINT_STATE_SCALARS + c) * 64 + lane] = v[c];
     }

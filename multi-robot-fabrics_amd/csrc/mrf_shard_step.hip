@@ -103,7 +103,12 @@ __global__ __launch_bounds__(64) void k_step_action_joints(const DevCfg<T>* __re
         if constexpr (REMOTE)
           remote_obstacles_joints<typename LS::Collision, LO>(
               cfg, xch, lane, first, count, N,
-              [&](int jr, int c) { return jst_all[((int64_t)slots.s[jr] * MRF_JOINT_STATE_SCALARS + c) * n_scen + scen]; }, E, acc);
+              [&](int jr, T (&v)[MRF_JOINT_STATE_SCALARS]) {
+#pragma unroll
+                for (int c = 0; c < MRF_JOINT_STATE_SCALARS; ++c)
+                  v[c] = jst_all[((int64_t)slots.s[jr] * MRF_JOINT_STATE_SCALARS + c) * n_scen + scen];
+              },
+              E, acc);
       },
       qdd, act);
   if (active) {

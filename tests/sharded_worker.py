@@ -59,7 +59,7 @@ def main():
     dist.all_gather_object(out, {"rank": rank, "first": sr.first, "count": sr.count, "err": max(errs), "exchange": info["exchange"],
                                  "scalars": info["exchange_scalars_per_robot"], "peers": h.comm_peer_info(),
                                  "peers_one_hop": info["peers_one_hop"], "coresident": info["coresident_workgroups"],
-                                 "paired": info["paired_blocks"]})
+                                 "paired": info["paired_blocks"], "tagged": info["tagged_payload"]})
     if rank == 0:
         print(json.dumps({"ranks": out}))
     dist.barrier()

@@ -150,6 +150,25 @@ def test_paired_blocks_processes_one_gpu(world, n_robots, horizon, n_scen, table
         assert r["err"] < (1e-9 if dtype == "f64" else 2e-3), ranks
 
 
+@pytest.mark.parametrize("world,n_robots,horizon,n_scen,table,dtype,max_grid", [
+    (2, 2, 6, 150, "lo", "f64", 2),           # three blocks on two workgroups: the tags keep counting across blocks and rollouts
+    (3, 3, 5, 100, "lo", "f64", 0),           # one robot per rank: two tagged joint states polled per lane and step
+    (2, 3, 4, 60, "offsets", "f64", 0),       # 2 + 1 robots, generic table: the staged (rolled-walk) receiver
+    (4, 8, 3, 12, "offsets20", "f64", 0),     # BASELINE config 5's table on 4 ranks: six remote robots per lane
+    (2, 2, 5, 70, "lo", "f32", 0),            # float32: one tagged word per scalar
+])
+def test_tagged_payload_processes_one_gpu(world, n_robots, horizon, n_scen, table, dtype, max_grid):
+    """MRF_PEER_TAGGED=1 (opt-in): the joint state travels as 8-byte words that carry the tag of their step and are polled by the
+    reader directly -- no store drain, no flags.  Separate processes, IPC-mapped buffers, three rollouts back to back."""
+    env = {"MRF_PEER_TAGGED": "1"}
+    if max_grid:
+        env["MRF_PEER_MAX_GRID"] = str(max_grid)
+    ranks = _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, "joints", 29557, extra_env=env)
+    for r in ranks:
+        assert r["tagged"] == 1 and r["paired"] == 0, ranks
+        assert r["err"] < (1e-9 if dtype == "f64" else 2e-3), ranks
+
+
 def test_plain_c_consumer_two_processes_one_gpu():
     """The same two-process peer exchange driven from plain C++ (examples/sharded_rollout_c.cpp: fork, pipes for the IPC
     handles, mrf_comm_peer_open / _connect, mrf_rollout_sharded) -- a non-Python consumer of the ABI runs the north-star
@@ -162,12 +181,14 @@ def test_plain_c_consumer_two_processes_one_gpu():
     assert out.stdout.count("rel err vs fused kernel") == 2, out.stdout
 
 
-def test_peer_timeout_is_loud_and_recoverable():
+@pytest.mark.parametrize("tagged", [0, 1])
+def test_peer_timeout_is_loud_and_recoverable(tagged):
     """A peer that skips a rollout: the waiting rank's exchange times out (bounded), its rollout leaves q / qdot alone and
     returns NaN, mrf_comm_status reports it ON BOTH RANKS; mrf_comm_reset on every rank between two barriers makes the
     group usable again although the ranks had issued different numbers of rollouts.  Then a peer that arrives late:
     neither rank may return a finite result (tests/timeout_worker.py)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="400", MRF_PEER_DEVICE_SHARE="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="400", MRF_PEER_DEVICE_SHARE="2",
+               MRF_PEER_TAGGED=str(tagged))      # 1: the bounded wait is the poll of the tagged payload words themselves
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "tests", "timeout_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
@@ -310,4 +331,26 @@ def test_in_process_group_paired_blocks_reproduce_single_blocks(monkeypatch):
                 assert torch.equal(a, a0) and torch.equal(q, q0) and torch.equal(qd, qd0)      # the same kernel twice: bit-equal
             else:
                 assert rel(a, a0) < 1e-12 and rel(q, q0) < 1e-12 and rel(qd, qd0) < 1e-12
+    grp.close()
+
+
+@pytest.mark.parametrize("n_robots,G,n_scen,horizon", [(3, 3, 21504, 6), (4, 4, 8192, 4), (3, 2, 10752 + 13, 5)])
+def test_in_process_group_tagged_payload(n_robots, G, n_scen, horizon, monkeypatch):
+    """The tagged payload at production grid sizes (several blocks per workgroup, a ragged last block), all ranks in this process."""
+    from multi_robot_fabrics_amd.sharded import InProcessGroup
+    monkeypatch.setenv("MRF_PEER_TAGGED", "1")
+    cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+    cfg.goal_estimate_mask = ((1 << n_robots) - 1) & ~1
+    batch = scenarios.tiled_batch(cfg, n_scen, seed=6, **({"x_min": 0.3, "q_spread": 0.15} if n_robots > 3 else {}))
+    ref = FabricHandle(cfg, 0)
+    want, tq, tqd = ref.rollout(*(ref.tensor(batch[k]) for k in ("q", "qdot", "params")), want_traj=True)
+    grp = InProcessGroup(cfg, G, n_scen)
+    rows = [grp.own_rows(g, n_scen) for g in range(G)]
+    for rep in range(3):
+        states = [tuple(ref.tensor(np.ascontiguousarray(batch[k][:, r.numpy()])) for k in ("q", "qdot", "params")) for r in rows]
+        avgs = grp.rollout(states)
+        for g, (avg, r) in enumerate(zip(avgs, rows)):
+            r = r.cuda()
+            assert rel(avg, want[r]) < 1e-9 and rel(states[g][0], tq[-1][:, r]) < 1e-9 and rel(states[g][1], tqd[-1][:, r]) < 1e-9
+    assert all(h.comm_info()["tagged_payload"] == 1 for h in grp.handles)
     grp.close()

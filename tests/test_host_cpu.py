@@ -331,11 +331,11 @@ def test_topology_and_exchange_schema_without_a_gpu():
     assert set(t) >= {"n_devices", "status", "can_access_peer", "link_type", "hops", "visible_devices_env"}, t
     assert len(t["can_access_peer"]) == len(t["link_type"]) == len(t["hops"]) == min(t["n_devices"], 16)
     assert set(bench.SHARDED_KEYS) >= {"exchange", "allgather_bytes_per_rank_per_step", "roofline", "ranks", "parity_vs_fused_kernel"}
-    assert abi.COMM_INFO_KEYS[10:] == ("exchange", "exchange_scalars_per_robot", "peers_one_hop", "coresident_workgroups", "paired_blocks")
-    assert len(abi.COMM_INFO_KEYS) == 15
+    assert abi.COMM_INFO_KEYS[10:] == ("exchange", "exchange_scalars_per_robot", "peers_one_hop", "coresident_workgroups", "paired_blocks", "tagged_payload")
+    assert len(abi.COMM_INFO_KEYS) == 16
     assert abi.PEER_INFO_KEYS == ("device", "can_access_peer", "link_type", "hops")
     header = open(os.path.join(ROOT, "include", "mrf.h")).read()
-    assert "#define MRF_COMM_INFO_N 15" in header and "#define MRF_PEER_INFO_N 4" in header
+    assert "#define MRF_COMM_INFO_N 16" in header and "#define MRF_PEER_INFO_N 4" in header
     assert "#define MRF_JOINT_STATE_SCALARS 21" in header and abi.JOINT_STATE_SCALARS == 21
     cfg = config.panda_config(n_robots=3, horizon=2)
     assert cfg.exchange == abi.EXCHANGE_JOINTS                       # the default payload

@@ -29,8 +29,9 @@ def main():
     ref = FabricHandle(cfg, 0)
     out = {"scenarios": B, "robots": N, "horizon": H, "ranks": G, "modes": {}}
     for mode, xk, paired in (("joints_paired", abi.EXCHANGE_JOINTS, "1"), ("joints_single", abi.EXCHANGE_JOINTS, "0"),
-                             ("spheres", abi.EXCHANGE_SPHERES, "0")):
+                             ("joints_tagged", abi.EXCHANGE_JOINTS, "0"), ("spheres", abi.EXCHANGE_SPHERES, "0")):
         os.environ["MRF_PEER_PAIRED"] = paired
+        os.environ["MRF_PEER_TAGGED"] = "1" if mode == "joints_tagged" else "0"
         c = cfg.copy()
         c.exchange = xk
         grp = InProcessGroup(c, G, B)

@@ -44,10 +44,13 @@ def main():
     res = {"scenarios": B, "robots": N, "horizon": H, "fused_ms": fused_ms, "groups": {}}
     for G in groups:
         # joints_paired: blocks in pairs where there is more than one per workgroup (k_rollout_peer_paired, opt-in)
-        for xname, xk in (("joints", abi.EXCHANGE_JOINTS), ("joints_paired", abi.EXCHANGE_JOINTS), ("spheres", abi.EXCHANGE_SPHERES)):
+        # joints_tagged: the payload words carry the tag of their step and are polled directly, no flags (MRF_PEER_TAGGED=1, opt-in)
+        for xname, xk in (("joints", abi.EXCHANGE_JOINTS), ("joints_paired", abi.EXCHANGE_JOINTS), ("joints_tagged", abi.EXCHANGE_JOINTS),
+                          ("spheres", abi.EXCHANGE_SPHERES)):
             c = cfg.copy()
             c.exchange = xk
             os.environ["MRF_PEER_PAIRED"] = "1" if xname == "joints_paired" else "0"
+            os.environ["MRF_PEER_TAGGED"] = "1" if xname == "joints_tagged" else "0"
             grp = InProcessGroup(c, G, B)
             rows = [grp.own_rows(g, B) for g in range(G)]
             base = [tuple(ref.tensor(np.ascontiguousarray(batch[k][:, r.numpy()])) for k in ("q", "qdot", "params")) for r in rows]
@@ -81,7 +84,7 @@ def main():
             info = grp.handles[0].comm_info()
             res["groups"][f"G{G}_{xname}"] = {"ranks": G, "robots_per_rank": [cnt for _, cnt in grp.parts], "exchange": xname,
                                              "ms_per_group_rollout_wall": ms, "ms_device_slowest_rank": dev_ms, "vs_fused": dev_ms / fused_ms, "rel_err_vs_fused": err,
-                                             "scalars_per_robot": info["exchange_scalars_per_robot"], "paired_blocks": info["paired_blocks"]}
+                                             "scalars_per_robot": info["exchange_scalars_per_robot"], "paired_blocks": info["paired_blocks"], "tagged_payload": info["tagged_payload"]}
             grp.close()
     print(json.dumps(res))
 
