@@ -84,7 +84,17 @@ def test_comm_argument_errors():
     assert h.comm_partition() == (0, 2)
 
 
+def _free_port():
+    """A port nobody listens on right now: back-to-back launches on ONE fixed rendezvous port can meet the previous
+    launch's socket still closing."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port, roll_call=False, extra_env=None):
+    port = _free_port()         # the callers' fixed numbers are kept for reading the logs only
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="8000", MRF_PEER_DEVICE_SHARE=str(world))
     env.update(extra_env or {})
     if roll_call:       # the residency roll call of mrf_comm_peer_connect runs although the ranks share the device
@@ -190,7 +200,7 @@ def test_peer_timeout_is_loud_and_recoverable(tagged):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRF_PEER_TIMEOUT_MS="400", MRF_PEER_DEVICE_SHARE="2",
                MRF_PEER_TAGGED=str(tagged))      # 1: the bounded wait is the poll of the tagged payload words themselves
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "tests", "timeout_worker.py")]
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "timeout_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     ranks = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["ranks"]
