@@ -129,6 +129,10 @@ class HipStepBackend:
     def action_joints(self, n_scen, first, count, q, qd_io, prm, jst_all, sumsq):
         self.h.step_action_joints(n_scen, first, count, q, qd_io, prm, jst_all, sumsq)
 
+    def action_predict_joints(self, n_scen, first, count, q_io, qd_io, prm, jst_all, sumsq, jst_next_own):
+        """The action of this step and the position update + joint state of the following one in ONE launch."""
+        self.h.step_action_predict_joints(n_scen, first, count, q_io, qd_io, prm, jst_all, sumsq, jst_next_own)
+
 
 class ShardedRollout:
     def __init__(self, cfg, rank, world, backend=None, device_index=0, transport="torch", max_scenarios=None):
@@ -237,14 +241,21 @@ class ShardedRollout:
         sumsq = torch.zeros((n_scen * self.count,), dtype=self.dtype, device=self.device)
         if (self.cfg.goal_estimate_mask >> self.first) & ((1 << self.count) - 1):
             prm = self.backend.prepare(n_scen, self.first, self.count, q, qd, prm)     # RF-CV goal estimate (EXC:355-357)
-        for _ in range(H):
-            predict(n_scen, self.first, self.count, q, qd, own[:self.count])
+        # joint payload: from the second step on, the action launch of step k also does the position update of step k + 1 and
+        # writes its joint state into the send block (mrf_step_action_predict_joints: what the in-library RCCL loop runs)
+        fused = self.joints and hasattr(self.backend, "action_predict_joints")
+        for k in range(H):
+            if k == 0 or not fused:
+                predict(n_scen, self.first, self.count, q, qd, own[:self.count])
             if self.G > 1:
                 dist.all_gather_into_tensor(pad.view(-1), own.view(-1), group=self.group)
             everybody = pad.view((self.G * self.cnt_max,) + shape + (n_scen,))
             if not self.uniform:
                 everybody = everybody.index_select(0, self._unpad)
-            action(n_scen, self.first, self.count, q, qd, prm, everybody, sumsq)
+            if fused and k + 1 < H:
+                self.backend.action_predict_joints(n_scen, self.first, self.count, q, qd, prm, everybody, sumsq, own[:self.count])
+            else:
+                action(n_scen, self.first, self.count, q, qd, prm, everybody, sumsq)
         return sumsq / (H * 7)
 
     # ------------------------------------------------------------------ bench leg (bench.py --shard robots)

@@ -29,6 +29,27 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("exchange", ["joints", "spheres"])
+@pytest.mark.parametrize("n_robots,horizon,n_scen,table", [(3, 6, 37, "lo"), (3, 4, 21, "offsets")])
+def test_world1_torch_transport_matches_fused_rollout(n_robots, horizon, n_scen, table, exchange):
+    """The Python fallback transport (the step kernels driven from Python; joint payload: one launch per step from the second
+    step on, the group of one gathering in place) against the fused kernel."""
+    cfg = config.panda_config(n_robots=n_robots, horizon=horizon)
+    cfg.exchange = {"joints": abi.EXCHANGE_JOINTS, "spheres": abi.EXCHANGE_SPHERES}[exchange]
+    cfg.goal_estimate_mask = 0b110 & ((1 << n_robots) - 1)
+    if table == "offsets":
+        links, offs = config.sphere_offsets_per_link(2)
+        config.set_spheres(cfg, links, offs, [0.06] * len(links))
+    batch = scenarios.panda_batch(cfg, n_scen, seed=5)
+    sr = ShardedRollout(cfg, 0, 1, device_index=0, transport="torch")
+    h = sr.backend.h
+    q, qd, prm = (h.tensor(batch[k]) for k in ("q", "qdot", "params"))
+    want_avg, tq, tqd = FabricHandle(cfg, 0).rollout(q, qd, prm, want_traj=True)
+    qq, qqd = q.clone(), qd.clone()
+    avg = sr.rollout(qq, qqd, prm)
+    assert rel(avg, want_avg) < 1e-9 and rel(qq, tq[-1]) < 1e-9 and rel(qqd, tqd[-1]) < 1e-9
+
+
+@pytest.mark.parametrize("exchange", ["joints", "spheres"])
 @pytest.mark.parametrize("transport", ["rccl", "peer"])
 @pytest.mark.parametrize("n_robots,horizon,n_scen,table", [(3, 6, 37, "lo"), (2, 5, 130, "lo"), (3, 4, 21, "offsets")])
 def test_world1_matches_fused_rollout(transport, n_robots, horizon, n_scen, table, exchange):

@@ -102,6 +102,13 @@ class OracleStepBackend:
         self.action(n_scen, first, count, q, qd_io, prm, torch.from_numpy(full.transpose(3, 0, 1, 2).copy()), sumsq)
 
 
+    def action_predict_joints(self, n_scen, first, count, q_io, qd_io, prm, jst_all, sumsq, jst_next_own):
+        """mrf_step_action_predict_joints: the action of this step, then the position update and joint state of the next.
+        jst_all is read before jst_next_own is written (a group of one gathers in place)."""
+        self.action_joints(n_scen, first, count, q_io, qd_io, prm, jst_all.clone(), sumsq)
+        self.predict_joints(n_scen, first, count, q_io, qd_io, jst_next_own)
+
+
 def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir, exchange="joints"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
