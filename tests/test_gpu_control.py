@@ -320,7 +320,9 @@ def test_rollout_clock_probe():
     e1.record()
     c = h.rollout_clock()
     assert 0.5 < c["shader_ghz_first_workgroup"] < 3.5 and 0.5 < c["shader_ghz_last_workgroup"] < 3.5
-    assert 0 < c["first_workgroup_ms"] <= e0.elapsed_time(e1) * 1.05 and 0 < c["last_workgroup_ms"] <= e0.elapsed_time(e1) * 1.05
+    # two clocks (the kernel's wall_clock64 stamps, the HIP events around the launch): generous slack, this is a sanity bound
+    bound = e0.elapsed_time(e1) * 1.3 + 0.05
+    assert 0 < c["first_workgroup_ms"] <= bound and 0 < c["last_workgroup_ms"] <= bound
 
 
 def test_comm_info_without_a_communicator():
