@@ -54,7 +54,9 @@ def main():
     errs = []
     for _ in range(2):
         q, qd = q0.clone(), qd0.clone()
-        avg = sr.rollout(q, qd, prm)
+        torch.cuda.synchronize()
+        dist.barrier()          # the ranks enter together (the time-out under test is 0.4 s: a rank still loading code objects
+        avg = sr.rollout(q, qd, prm)   # for the reference rollout above must not look like a missing peer)
         h.comm_status()
         errs.append(float((avg - want).abs().max() / want.abs().max()))
     report["err_after_reset"] = max(errs)
@@ -78,6 +80,8 @@ def main():
     h.comm_reset()                                    # second reset: epoch 2 of the sequence numbers
     dist.barrier()
     q, qd = q0.clone(), qd0.clone()
+    torch.cuda.synchronize()
+    dist.barrier()
     avg = sr.rollout(q, qd, prm)
     h.comm_status()
     report["err_after_second_reset"] = float((avg - want).abs().max() / want.abs().max())
