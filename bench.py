@@ -35,14 +35,37 @@ import numpy as np
 SHARD_TIMEOUT_RC = 3   # a hung exchange in a process that has touched the GPU must not look like a clean run
 
 
+def free_port():
+    """A TCP port for a rendezvous that is about to be started by ANOTHER process: free right now and BELOW the kernel's
+    ephemeral range, so that no outgoing connection (the collectives' bootstrap opens many) can take it between this probe
+    and the listener's bind -- a port from bind(0) met exactly that in 1 of ~25 launches (EADDRINUSE)."""
+    import random
+    import socket
+    lo = 32768
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo = int(f.read().split()[0])
+    except (OSError, ValueError):
+        pass
+    top = max(min(lo, 32768), 12000)
+    for _ in range(64):
+        port = random.randrange(10000, top)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+                return port
+            except OSError:
+                continue
+    with socket.socket() as sk:        # nothing free in 64 draws: fall back to the kernel's choice
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def spawn_ranks(argv, n):
     """`python bench.py --gpus N` without a launcher: start one process per GPU through torch.distributed.run as a child
     process.  Nothing in this (parent) process has initialised the GPU at this point, and it never will."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
@@ -463,10 +486,7 @@ def robot_sharded_in_children(args, rank, world, guard_s, child_cmd=None):
     import torch.distributed as dist
     port = [None]
     if rank == 0:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port[0] = sk.getsockname()[1]
+        port[0] = free_port()
     dist.broadcast_object_list(port, src=0)
     # the launcher's agent store belongs to the parents' group: the children rendezvous on a port of their own
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}

@@ -13,9 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def run_parents(mode, guard_s):
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    port = bench.free_port()        # below the ephemeral range: no outgoing connection can take it before the parents bind it
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "bench_children_worker.py"), str(r), "2", str(port), str(guard_s), mode],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]

@@ -106,12 +106,12 @@ def test_comm_argument_errors():
 
 
 def _free_port():
-    """A port nobody listens on right now: back-to-back launches on ONE fixed rendezvous port can meet the previous
-    launch's socket still closing."""
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
+    """A port nobody listens on right now and no outgoing connection can take (below the ephemeral range): bench.free_port.
+    Back-to-back launches on ONE fixed rendezvous port met the previous launch's socket still closing, a port from bind(0)
+    met an outgoing connection (EADDRINUSE in 1 of ~25 launches each)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.free_port()
 
 
 def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchange, port, roll_call=False, extra_env=None):
@@ -124,6 +124,9 @@ def _run_group_on_one_gpu(world, n_robots, horizon, n_scen, table, dtype, exchan
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_worker.py"), str(n_robots),
            str(horizon), str(n_scen), table, dtype, exchange]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    if out.returncode != 0 and "EADDRINUSE" in out.stderr:      # the rendezvous port was taken after all: once more, another port
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)["ranks"]

@@ -132,9 +132,12 @@ def _worker(rank, world, port, n_robots, horizon, n_scen, out_dir, exchange="joi
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """bench.free_port: free now and below the ephemeral range (a port from bind(0) can be taken by an outgoing connection
+    before the rendezvous binds it)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.free_port()
 
 
 @pytest.mark.parametrize("exchange", ["joints", "spheres"])
