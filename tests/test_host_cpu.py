@@ -345,3 +345,24 @@ def test_topology_and_exchange_schema_without_a_gpu():
     rc = abi.load_library().mrf_create(C.byref(c2), 0, C.byref(out))
     assert rc == -2 and b"exchange" in abi.load_library().mrf_last_error(out)     # MRF_E_CONFIG, before any device is touched
     abi.load_library().mrf_destroy(out)
+
+
+def test_free_port_is_bindable_and_below_the_ephemeral_range():
+    """bench.free_port: the rendezvous ports handed to OTHER processes (self-spawned ranks, the robot-sharded block's children,
+    the multi-process tests) are free now and cannot be taken by an outgoing connection before the listener binds them."""
+    import socket
+    import bench
+    lo = 32768
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo = int(f.read().split()[0])
+    except (OSError, ValueError):
+        pass
+    seen = set()
+    for _ in range(8):
+        port = bench.free_port()
+        assert 10000 <= port < max(min(lo, 32768), 12000)
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", port))
+        seen.add(port)
+    assert len(seen) > 1          # drawn at random, not one fixed number
